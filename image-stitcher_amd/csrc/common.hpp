@@ -1,0 +1,97 @@
+// Shared host-side plumbing of libmistitch: error reporting, the context object,
+// grow-only device workspaces.  No kernels here.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "../../include/mistitch.h"
+
+namespace mistitch {
+
+// ---- last-error string (one per calling thread) ---------------------------
+inline char* last_error_buf() {
+  static thread_local char buf[512] = {0};
+  return buf;
+}
+
+inline int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(last_error_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define MS_HIP(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e__ = (expr);                                                              \
+    if (e__ != hipSuccess)                                                                \
+      return ::mistitch::set_error(MISTITCH_ERR_HIP, "%s failed: %s (%s:%d)", #expr,      \
+                                   hipGetErrorString(e__), __FILE__, __LINE__);           \
+  } while (0)
+
+#define MS_REQUIRE(cond, code, ...)                                   \
+  do {                                                                \
+    if (!(cond)) return ::mistitch::set_error((code), __VA_ARGS__);   \
+  } while (0)
+
+// ---- grow-only device buffer ------------------------------------------------
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t want) {
+    if (want <= bytes) return MISTITCH_OK;
+    if (ptr) {
+      MS_HIP(hipFree(ptr));
+      ptr = nullptr;
+      bytes = 0;
+    }
+    hipError_t e = hipMalloc(&ptr, want);
+    if (e != hipSuccess) {
+      ptr = nullptr;
+      return set_error(MISTITCH_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    bytes = want;
+    return MISTITCH_OK;
+  }
+  void release() {
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr;
+    bytes = 0;
+  }
+};
+
+// ---- FFT plan (one per length and precision), tables live on the device ------
+struct FftPlanDev {
+  int n;
+  int npass;
+  int radix[6];
+  const void* tw;             // n complex entries exp(-2 pi i k / n), precision of the plan
+  const uint16_t* pos2freq;   // storage position -> frequency index (digit-reversed order)
+  const uint16_t* freq2pos;   // inverse of pos2freq
+  const uint16_t* mpos;       // storage position of the negated frequency
+};
+
+struct FftPlanHost {
+  FftPlanDev dev{};
+  void* blob = nullptr;  // single device allocation backing the tables
+};
+
+}  // namespace mistitch
+
+// The opaque handle of the C ABI.
+struct mistitch_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int pair_chunk = 32;  // pairs processed per pipeline pass (bounds the FFT workspace)
+  std::map<long long, mistitch::FftPlanHost> plans;  // key = n * 2 + (is_f64)
+  mistitch::DevBuf desc, staging, spectrum, partial, peaks, cand, acc, misc, bins;
+  std::vector<char> host_scratch;
+};

@@ -1,0 +1,1094 @@
+// Pairwise registration kernels and their C entry points.
+//
+// Canonical strip layout.  Every strip is processed as [S][L] with the long
+// axis L contiguous: a "top" strip (w rows of the tile) is read in place with
+// S = w, L = tile width; a "left" strip (w columns of the tile) is transposed
+// once into a staging buffer with S = w, L = tile height.  The 2-D DFT, the
+// phase-correlation peak set and every NCC moment are invariant under that
+// transposition; only the reported (row, col) are swapped back.
+//
+// Pipeline per pass of pairs (all kernels skip pairs whose status is set):
+//   k_setup_pairs      descriptors from (pair_idx, pair_dir)
+//   k_edge_stats       exact variance of the 16-strided sample -> featureless
+//   k_transpose_strips left strips -> staging [S][L]
+//   k_fft_long_fwd     z = a + i b per line, length-L FFT, digit-reversed out
+//   k_fft_short_cps    length-S FFT down columns, split into the two spectra,
+//                      normalised cross-power spectrum, inverse length-S FFT;
+//                      only the Hermitian half of the columns is written back
+//   k_fft_long_inv     two lines per complex inverse FFT, scale, top-k per block
+//   k_peaks_candidates merge block top-k, emit the 32 signed candidates
+//   k_ncc_accumulate   exact integer moments of every candidate overlap
+//   k_finalize         NCC from the moments, first strict maximum wins
+#include <algorithm>
+#include <cmath>
+#include <limits>
+
+#include "common.hpp"
+#include "fft.hpp"
+
+namespace mistitch {
+
+constexpr int kThreads = 256;
+constexpr int kMaxK = 16;       // peaks a block / a pair can report
+constexpr int kNumCand = 32;    // 2 peaks x 16 signed interpretations
+constexpr int kNccChunks = 32;  // workgroups cooperating on one candidate
+
+struct PairDesc {
+  const uint16_t* a;  // canonical strip of the first tile
+  const uint16_t* b;  // canonical strip of the second tile
+  int64_t pitch;      // elements between canonical lines
+  int S, L;           // canonical extents
+  int transposed;     // 1: canonical (s, l) = image (col, row)
+  int img_h, img_w;   // strip extents in image orientation
+  int off_y, off_x;   // strip origin inside the first tile
+};
+
+struct Peak {
+  double val;
+  int key;  // flat index in image orientation; -1 = none
+  int loc;  // block-local location (selection bookkeeping)
+};
+
+struct Cand {
+  int y, x;    // image orientation, strip relative
+  int flag;    // 0 evaluate, 1 empty overlap (skipped), 2 fewer than 25 pixels, 3 duplicate
+  int dup_of;  // index of the earlier identical candidate when flag == 3
+};
+
+__device__ __forceinline__ bool peak_better(double v, int k, double bv, int bk) {
+  return (v > bv) || (v == bv && k > bk);
+}
+
+// Block-wide argmax of (val, key) carrying loc; result valid in every thread.
+__device__ __forceinline__ Peak block_argmax(Peak mine, Peak* red /*[kThreads/64]*/) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double ov = __shfl_xor(mine.val, off);
+    int ok = __shfl_xor(mine.key, off);
+    int ol = __shfl_xor(mine.loc, off);
+    if (peak_better(ov, ok, mine.val, mine.key)) {
+      mine.val = ov;
+      mine.key = ok;
+      mine.loc = ol;
+    }
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = mine;
+  __syncthreads();
+  Peak best = red[0];
+#pragma unroll
+  for (int w = 1; w < kThreads / 64; ++w) {
+    Peak o = red[w];
+    if (peak_better(o.val, o.key, best.val, best.key)) best = o;
+  }
+  return best;
+}
+
+// ---------------------------------------------------------------------------
+__global__ void k_setup_pairs(const uint16_t* tiles, int64_t tile_pitch, int H, int W, int w_left,
+                              int w_top, const int32_t* pair_idx, const uint8_t* pair_dir, int n_pairs,
+                              int n_tiles, uint16_t* staging, int pair_chunk, PairDesc* desc,
+                              int8_t* status) {
+  int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  int i1 = pair_idx[2 * p], i2 = pair_idx[2 * p + 1];
+  PairDesc d;
+  int st = MISTITCH_PAIR_OK;
+  if (i1 < 0 || i2 < 0 || i1 >= n_tiles || i2 >= n_tiles) {
+    st = MISTITCH_PAIR_FEATURELESS;  // unusable pair: reported like a failed one
+    i1 = i2 = 0;
+  }
+  const uint16_t* t1 = tiles + (int64_t)i1 * tile_pitch;
+  const uint16_t* t2 = tiles + (int64_t)i2 * tile_pitch;
+  if (pair_dir[p] == 0) {  // left: last w columns of t1 against first w columns of t2
+    int slot = p % pair_chunk;
+    uint16_t* st_a = staging + (int64_t)slot * 2 * w_left * H;
+    d.a = st_a;
+    d.b = st_a + (int64_t)w_left * H;
+    d.pitch = H;
+    d.S = w_left;
+    d.L = H;
+    d.transposed = 1;
+    d.img_h = H;
+    d.img_w = w_left;
+    d.off_y = 0;
+    d.off_x = W - w_left;
+  } else {  // top: last w rows of t1 against first w rows of t2
+    d.a = t1 + (int64_t)(H - w_top) * W;
+    d.b = t2;
+    d.pitch = W;
+    d.S = w_top;
+    d.L = W;
+    d.transposed = 0;
+    d.img_h = w_top;
+    d.img_w = W;
+    d.off_y = H - w_top;
+    d.off_x = 0;
+  }
+  desc[p] = d;
+  status[p] = (int8_t)st;
+}
+
+// Exact population variance of strip[::16, ::16] from integer moments.
+__device__ __forceinline__ double sampled_variance(const uint16_t* base, int64_t pitch, int h, int w,
+                                                   unsigned long long* red) {
+  const int nr = (h + 15) / 16, nc = (w + 15) / 16;
+  unsigned long long s = 0, q = 0;
+  for (int e = threadIdx.x; e < nr * nc; e += blockDim.x) {
+    int r = e / nc, c = e - r * nc;
+    unsigned long long v = base[(int64_t)(16 * r) * pitch + 16 * c];
+    s += v;
+    q += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red[2 * wave] = s;
+    red[2 * wave + 1] = q;
+  }
+  __syncthreads();
+  s = q = 0;
+  for (int i = 0; i < (int)blockDim.x / 64; ++i) {
+    s += red[2 * i];
+    q += red[2 * i + 1];
+  }
+  const double n = (double)(nr * nc);
+  const double mean = (double)s / n;
+  return (double)q / n - mean * mean;
+}
+
+// grid (2, n_pairs): which strip, pair.
+__global__ void k_edge_stats(const uint16_t* tiles, int64_t tile_pitch, int H, int W, int w_left,
+                             int w_top, const int32_t* pair_idx, const uint8_t* pair_dir,
+                             int8_t* status, double threshold) {
+  __shared__ unsigned long long red[2 * kThreads / 64];
+  const int p = blockIdx.y, which = blockIdx.x;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const uint16_t* t = tiles + (int64_t)pair_idx[2 * p + which] * tile_pitch;
+  const uint16_t* base;
+  int h, w;
+  if (pair_dir[p] == 0) {
+    h = H;
+    w = w_left;
+    base = which == 0 ? t + (W - w_left) : t;
+  } else {
+    h = w_top;
+    w = W;
+    base = which == 0 ? t + (int64_t)(H - w_top) * W : t;
+  }
+  double var = sampled_variance(base, W, h, w, red);
+  if (threadIdx.x == 0 && var < threshold) status[p] = MISTITCH_PAIR_FEATURELESS;
+}
+
+__global__ void k_variance_single(const uint16_t* strip, int64_t pitch, int h, int w, double* out) {
+  __shared__ unsigned long long red[2 * kThreads / 64];
+  double var = sampled_variance(strip, pitch, h, w, red);
+  if (threadIdx.x == 0) out[0] = var;
+}
+
+// Left strips into canonical [S][L]: staging[s][l] = tile[l][x0 + s].
+// grid (ceil(L/32), ceil(S/32), 2 * pairs_in_pass), block (32, 8).
+__global__ void k_transpose_strips(const uint16_t* tiles, int64_t tile_pitch, int H, int W, int w_left,
+                                   const int32_t* pair_idx, const PairDesc* desc, const int8_t* status,
+                                   int pair0) {
+  __shared__ uint16_t tile[32][33];
+  const int p = pair0 + (blockIdx.z >> 1), which = blockIdx.z & 1;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  if (!d.transposed) return;
+  const uint16_t* src = tiles + (int64_t)pair_idx[2 * p + which] * tile_pitch + (which == 0 ? W - w_left : 0);
+  uint16_t* dst = const_cast<uint16_t*>(which == 0 ? d.a : d.b);
+  const int l0 = blockIdx.x * 32, s0 = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    int l = l0 + r, s = s0 + threadIdx.x;
+    if (l < H && s < w_left) tile[r][threadIdx.x] = src[(int64_t)l * W + s];
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    int s = s0 + r, l = l0 + threadIdx.x;
+    if (l < H && s < w_left) dst[(int64_t)s * H + l] = tile[threadIdx.x][r];
+  }
+}
+
+// Generic transposing copy used by the single-strip entry points (tall strips).
+__global__ void k_transpose_plain(const uint16_t* src, int64_t pitch, int h, int w, uint16_t* dst) {
+  __shared__ uint16_t tile[32][33];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    int y = r0 + r, x = c0 + threadIdx.x;
+    if (y < h && x < w) tile[r][threadIdx.x] = src[(int64_t)y * pitch + x];
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += 8) {
+    int x = c0 + r, y = r0 + threadIdx.x;
+    if (y < h && x < w) dst[(int64_t)x * h + y] = tile[threadIdx.x][r];
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Forward FFT along the long axis.  grid (S / NF, pairs_in_pass).
+template <typename T, bool VEC>
+__global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc, const int8_t* status,
+                                                           int pair0, int S, int L, int want_transposed,
+                                                           FftPlanDev planL, int NF, cx<T>* spectrum) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  const int tid = threadIdx.x;
+  LineAddr<T> addr{LineAddr<T>::padded(L) + 1};
+  const int s0 = blockIdx.x * NF;
+  if constexpr (VEC) {
+    for (int e = tid * 8; e < NF * L; e += kThreads * 8) {
+      const int f = e / L, i = e - f * L;
+      const uint4 va = *reinterpret_cast<const uint4*>(d.a + (int64_t)(s0 + f) * d.pitch + i);
+      const uint4 vb = *reinterpret_cast<const uint4*>(d.b + (int64_t)(s0 + f) * d.pitch + i);
+      const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        buf[addr(f, i + 2 * q)] = mk<T>((T)(wa[q] & 0xffffu), (T)(wb[q] & 0xffffu));
+        buf[addr(f, i + 2 * q + 1)] = mk<T>((T)(wa[q] >> 16), (T)(wb[q] >> 16));
+      }
+    }
+  } else {
+    for (int e = tid; e < NF * L; e += kThreads) {
+      const int f = e / L, i = e - f * L;
+      buf[addr(f, i)] = mk<T>((T)d.a[(int64_t)(s0 + f) * d.pitch + i], (T)d.b[(int64_t)(s0 + f) * d.pitch + i]);
+    }
+  }
+  __syncthreads();
+  fft_forward<T>(buf, addr, NF, planL, tid, kThreads);
+  cx<T>* out = spectrum + ((int64_t)blockIdx.y * S + s0) * L;
+  for (int e = tid; e < NF * L; e += kThreads) {
+    const int f = e / L, i = e - f * L;
+    out[(int64_t)f * L + i] = buf[addr(f, i)];
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ T cabs_safe(T x, T y);
+template <>
+__device__ __forceinline__ double cabs_safe<double>(double x, double y) {
+  return sqrt(x * x + y * y);  // |x|,|y| <= 2^67: no overflow in double
+}
+template <>
+__device__ __forceinline__ float cabs_safe<float>(float x, float y) {
+  return hypotf(x, y);  // products of two 2^33 sums overflow float when squared
+}
+
+// Short-axis FFT, cross-power spectrum, short-axis inverse FFT.
+// grid (L / C, pairs_in_pass): one block of C adjacent storage positions plus
+// the block that holds their negated frequencies.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc, const int8_t* status,
+                                                            int pair0, int S, int L, int want_transposed,
+                                                            FftPlanDev planS, FftPlanDev planL, int C,
+                                                            cx<T>* spectrum, T eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  {
+    const PairDesc& d = desc[p];
+    if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  }
+  const int b = blockIdx.x;
+  const int mb = planL.mpos[b * C] / C;
+  if (mb < b) return;  // the partner block owns this pair of blocks
+  const bool self = (mb == b);
+  const int ncol = self ? C : 2 * C;
+  const int rs = 2 * C;
+  const int tid = threadIdx.x;
+  cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * L;
+  for (int e = tid; e < S * ncol; e += kThreads) {
+    const int s = e / ncol, c = e - s * ncol;
+    const int pos = c < C ? b * C + c : mb * C + (c - C);
+    buf[s * rs + c] = Z[(int64_t)s * L + pos];
+  }
+  __syncthreads();
+  ColAddr<T> addr{rs};
+  fft_forward<T>(buf, addr, ncol, planS, tid, kThreads);
+  for (int e = tid; e < S * C; e += kThreads) {
+    const int q = e / C, c = e - q * C;
+    const int mp = planL.mpos[b * C + c];
+    const int pc = self ? (mp - b * C) : (C + mp - mb * C);
+    const int q2 = planS.mpos[q];
+    if (self && (q2 * rs + pc) < (q * rs + c)) continue;  // the partner cell's owner writes both
+    const cx<T> z = buf[q * rs + c];
+    const cx<T> zm = buf[q2 * rs + pc];
+    // z = A + iB with A, B the spectra of the two real strips:
+    // A = (z + conj(zm)) / 2,  B = (z - conj(zm)) / (2i)
+    const T ax = (T)0.5 * (z.x + zm.x), ay = (T)0.5 * (z.y - zm.y);
+    const T bx = (T)0.5 * (z.y + zm.y), by = (T)-0.5 * (z.x - zm.x);
+    T fx = ax * bx + ay * by;  // A * conj(B)
+    T fy = ay * bx - ax * by;
+    const T inv = (T)1 / (cabs_safe<T>(fx, fy) + eps);
+    fx *= inv;
+    fy *= inv;
+    buf[q * rs + c] = mk<T>(fx, fy);
+    if (self && (q2 * rs + pc) != (q * rs + c)) buf[q2 * rs + pc] = mk<T>(fx, -fy);
+  }
+  __syncthreads();
+  fft_inverse<T>(buf, addr, C, planS, tid, kThreads);
+  for (int e = tid; e < S * C; e += kThreads) {
+    const int s = e / C, c = e - s * C;
+    Z[(int64_t)s * L + b * C + c] = buf[s * rs + c];
+  }
+}
+
+// Inverse FFT along the long axis, two lines per complex transform, then the
+// block's k largest values.  grid (S / (2 NF), pairs_in_pass).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc, const int8_t* status,
+                                                           int pair0, int S, int L, int want_transposed,
+                                                           FftPlanDev planL, int C, int NF,
+                                                           const cx<T>* spectrum, int k, Peak* partial,
+                                                           int partial_stride, double* pcm_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
+  __shared__ Peak red[kThreads / 64];
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  const int tid = threadIdx.x;
+  LineAddr<T> addr{LineAddr<T>::padded(L) + 1};
+  const int s0 = blockIdx.x * NF * 2;
+  const cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * L;
+  for (int e = tid; e < NF * L; e += kThreads) {
+    const int f = e / L, pos = e - f * L;
+    const int bp = pos / C;
+    const bool stored = (planL.mpos[bp * C] / C) >= bp;
+    const int src = stored ? pos : planL.mpos[pos];
+    cx<T> g1 = Z[(int64_t)(s0 + 2 * f) * L + src];
+    cx<T> g2 = Z[(int64_t)(s0 + 2 * f + 1) * L + src];
+    if (!stored) {
+      g1.y = -g1.y;
+      g2.y = -g2.y;
+    }
+    buf[addr(f, pos)] = mk<T>(g1.x - g2.y, g1.y + g2.x);  // g1 + i g2
+  }
+  __syncthreads();
+  fft_inverse<T>(buf, addr, NF, planL, tid, kThreads);
+  const double scale = 1.0 / ((double)S * (double)L);
+  if (pcm_out != nullptr) {
+    double* out = pcm_out + (int64_t)blockIdx.y * S * L;
+    for (int e = tid; e < NF * L; e += kThreads) {
+      const int f = e / L, l = e - f * L;
+      const cx<T> v = buf[addr(f, l)];
+      const int s = s0 + 2 * f;
+      if (d.transposed) {
+        out[(int64_t)l * S + s] = (double)v.x * scale;
+        out[(int64_t)l * S + s + 1] = (double)v.y * scale;
+      } else {
+        out[(int64_t)s * L + l] = (double)v.x * scale;
+        out[(int64_t)(s + 1) * L + l] = (double)v.y * scale;
+      }
+    }
+  }
+  if (k <= 0) return;
+  // k rounds of block argmax; a taken element is overwritten with -inf.
+  T* flat = reinterpret_cast<T*>(buf);
+  const T neg_inf = -std::numeric_limits<T>::infinity();
+  for (int round = 0; round < k; ++round) {
+    Peak mine{-INFINITY, -1, -1};
+    for (int e = tid; e < NF * L; e += kThreads) {
+      const int f = e / L, l = e - f * L;
+      const int a0 = addr(f, l);
+      const cx<T> v = buf[a0];
+      const int s = s0 + 2 * f;
+      const int key0 = d.transposed ? l * S + s : s * L + l;
+      const int key1 = d.transposed ? key0 + 1 : key0 + L;
+      const double v0 = (double)v.x * scale, v1 = (double)v.y * scale;
+      if (v.x != neg_inf && peak_better(v0, key0, mine.val, mine.key)) mine = Peak{v0, key0, 2 * a0};
+      if (v.y != neg_inf && peak_better(v1, key1, mine.val, mine.key)) mine = Peak{v1, key1, 2 * a0 + 1};
+    }
+    Peak best = block_argmax(mine, red);
+    if (tid == 0) {
+      partial[(int64_t)blockIdx.y * partial_stride + blockIdx.x * k + round] = best;
+      if (best.loc >= 0) flat[best.loc] = neg_inf;
+    }
+    __syncthreads();
+  }
+}
+
+// Merge the per-block peaks of one pair and emit the candidate table.
+// grid (n_pairs_in_pass), block kThreads.
+__global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* desc, const int8_t* status,
+                                                               int pair0, Peak* partial, int partial_stride,
+                                                               int nblk_direct, int nblk_transposed, int k,
+                                                               int n_peaks_used, Peak* peaks /*[P][kMaxK]*/,
+                                                               Cand* cand /*[P][kNumCand]*/,
+                                                               unsigned long long* acc /*[P][kNumCand][5]*/) {
+  __shared__ Peak red[kThreads / 64];
+  __shared__ Peak top[kMaxK];
+  const int p = pair0 + blockIdx.x;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  const int tid = threadIdx.x;
+  Peak* mine_list = partial + (int64_t)blockIdx.x * partial_stride;
+  const int n_entries = (d.transposed ? nblk_transposed : nblk_direct) * k;  // what k_fft_long_inv wrote
+  for (int round = 0; round < k; ++round) {
+    Peak mine{-INFINITY, -1, -1};
+    for (int e = tid; e < n_entries; e += kThreads) {
+      const Peak c = mine_list[e];
+      if (c.key >= 0 && c.loc != -2 && peak_better(c.val, c.key, mine.val, mine.key)) mine = Peak{c.val, c.key, e};
+    }
+    Peak best = block_argmax(mine, red);
+    if (tid == 0) {
+      top[round] = best;
+      if (best.loc >= 0) mine_list[best.loc].loc = -2;  // taken
+      peaks[(int64_t)p * kMaxK + round] = best;
+    }
+    __syncthreads();
+  }
+  if (cand == nullptr) return;
+  __shared__ Cand sc[kNumCand];
+  if (tid < kNumCand) {
+    const int pk = tid >> 4, t = tid & 15;
+    Cand c{0, 0, 1, -1};
+    if (pk < n_peaks_used && pk < k && top[pk].key >= 0) {
+      const int py = top[pk].key / d.img_w, px = top[pk].key - py * d.img_w;
+      const int ymag = (t & 8) ? d.img_h - py : py;
+      const int xmag = (t & 4) ? d.img_w - px : px;
+      c.y = (t & 2) ? ymag : -ymag;
+      c.x = (t & 1) ? xmag : -xmag;
+      const int ay = c.y < 0 ? -c.y : c.y, ax = c.x < 0 ? -c.x : c.x;
+      if (ay >= d.img_h || ax >= d.img_w) {
+        c.flag = 1;
+      } else if ((long long)(d.img_h - ay) * (d.img_w - ax) < 25) {
+        c.flag = 2;
+      } else {
+        c.flag = 0;
+      }
+    }
+    sc[tid] = c;
+    for (int i = 0; i < 5; ++i) acc[((int64_t)p * kNumCand + tid) * 5 + i] = 0ull;
+  }
+  __syncthreads();
+  if (tid < kNumCand) {
+    Cand c = sc[tid];
+    if (c.flag == 0) {
+      for (int e = 0; e < tid; ++e) {
+        const Cand o = sc[e];
+        if (o.flag == 0 && o.y == c.y && o.x == c.x) {
+          c.flag = 3;
+          c.dup_of = e;
+          break;
+        }
+      }
+    }
+    cand[(int64_t)p * kNumCand + tid] = c;
+  }
+}
+
+// Exact moments (sum a, sum b, sum a^2, sum b^2, sum ab) over the overlap of a
+// candidate shift.  grid (kNccChunks, kNumCand, pairs_in_pass).
+__global__ __launch_bounds__(kThreads) void k_ncc_accumulate(const PairDesc* desc, const int8_t* status,
+                                                             int pair0, const Cand* cand,
+                                                             unsigned long long* acc) {
+  __shared__ unsigned long long red[5 * kThreads / 64];
+  const int p = pair0 + blockIdx.z;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const Cand c = cand[(int64_t)p * kNumCand + blockIdx.y];
+  if (c.flag != 0) return;
+  const PairDesc d = desc[p];
+  const int ds = d.transposed ? c.x : c.y;
+  const int dl = d.transposed ? c.y : c.x;
+  const int s_lo = ds > 0 ? ds : 0, s_hi = d.S + (ds < 0 ? ds : 0);
+  const int l_lo = dl > 0 ? dl : 0, l_hi = d.L + (dl < 0 ? dl : 0);
+  const int ncols = l_hi - l_lo;
+  unsigned long long sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
+  for (int s = s_lo + blockIdx.x; s < s_hi; s += gridDim.x) {
+    const uint16_t* ra = d.a + (int64_t)s * d.pitch + l_lo;
+    const uint16_t* rb = d.b + (int64_t)(s - ds) * d.pitch + (l_lo - dl);
+    unsigned int ta = 0, tb = 0;  // a row holds at most 4096 values: sums fit 32 bits
+    for (int i = threadIdx.x; i < ncols; i += kThreads) {
+      const unsigned int va = ra[i], vb = rb[i];
+      ta += va;
+      tb += vb;
+      saa += (unsigned long long)va * va;
+      sbb += (unsigned long long)vb * vb;
+      sab += (unsigned long long)va * vb;
+    }
+    sa += ta;
+    sb += tb;
+  }
+  unsigned long long v[5] = {sa, sb, saa, sbb, sab};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) red[wave * 5 + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kThreads / 64; ++w) t += red[w * 5 + threadIdx.x];
+    atomicAdd(&acc[((int64_t)p * kNumCand + blockIdx.y) * 5 + threadIdx.x], t);
+  }
+}
+
+// ---- exact 128-bit helpers -------------------------------------------------
+struct U128 {
+  unsigned long long hi, lo;
+};
+__device__ __forceinline__ U128 mul64(unsigned long long a, unsigned long long b) {
+  return U128{__umul64hi(a, b), a * b};
+}
+__device__ __forceinline__ bool ge128(U128 a, U128 b) { return a.hi > b.hi || (a.hi == b.hi && a.lo >= b.lo); }
+__device__ __forceinline__ U128 sub128(U128 a, U128 b) {  // a >= b
+  U128 r;
+  r.lo = a.lo - b.lo;
+  r.hi = a.hi - b.hi - (a.lo < b.lo ? 1ull : 0ull);
+  return r;
+}
+__device__ __forceinline__ double to_double(U128 a) {
+  return (double)a.hi * 18446744073709551616.0 + (double)a.lo;
+}
+
+// Pearson correlation from exact moments over n samples; mirrors the special
+// cases of the reference's ncc(): constant-constant -> 1, constant-varying -> -inf.
+__device__ double ncc_from_moments(unsigned long long n, unsigned long long sa, unsigned long long sb,
+                                   unsigned long long saa, unsigned long long sbb, unsigned long long sab) {
+  const U128 n_ab = mul64(n, sab), a_b = mul64(sa, sb);
+  const U128 n_aa = mul64(n, saa), a_a = mul64(sa, sa);
+  const U128 n_bb = mul64(n, sbb), b_b = mul64(sb, sb);
+  const U128 va = sub128(n_aa, a_a), vb = sub128(n_bb, b_b);  // n * sum x^2 >= (sum x)^2
+  const bool za = (va.hi | va.lo) == 0, zb = (vb.hi | vb.lo) == 0;
+  if (za || zb) return (za && zb) ? 1.0 : -INFINITY;
+  double num;
+  if (ge128(n_ab, a_b))
+    num = to_double(sub128(n_ab, a_b));
+  else
+    num = -to_double(sub128(a_b, n_ab));
+  const double den = sqrt(to_double(va) * to_double(vb));
+  double r = num / den;
+  if (!(r == r) || r == INFINITY || r == -INFINITY) return -INFINITY;
+  return r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);
+}
+
+// One thread per pair walks the candidates in evaluation order.
+__global__ void k_finalize(const PairDesc* desc, const int8_t* status_in, int n_pairs, const Cand* cand,
+                           const unsigned long long* acc, double* out, int8_t* status) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  if (status_in[p] != MISTITCH_PAIR_OK) {
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    out[3 * p] = out[3 * p + 1] = out[3 * p + 2] = nan;
+    return;
+  }
+  const PairDesc d = desc[p];
+  double best = -INFINITY;
+  int by = 0, bx = 0;
+  double vals[kNumCand];
+  for (int c = 0; c < kNumCand; ++c) {
+    const Cand k = cand[(int64_t)p * kNumCand + c];
+    double v;
+    if (k.flag == 1) {
+      vals[c] = -INFINITY;
+      continue;  // empty overlap: not evaluated at all
+    } else if (k.flag == 2) {
+      v = -INFINITY;
+    } else if (k.flag == 3) {
+      v = vals[k.dup_of];
+    } else {
+      const unsigned long long* m = acc + ((int64_t)p * kNumCand + c) * 5;
+      const int ay = k.y < 0 ? -k.y : k.y, ax = k.x < 0 ? -k.x : k.x;
+      const unsigned long long n = (unsigned long long)(d.img_h - ay) * (unsigned long long)(d.img_w - ax);
+      v = ncc_from_moments(n, m[0], m[1], m[2], m[3], m[4]);
+    }
+    vals[c] = v;
+    if (v > best) {
+      best = v;
+      by = k.y;
+      bx = k.x;
+    }
+  }
+  out[3 * p] = best;
+  out[3 * p + 1] = (double)(by + d.off_y);
+  out[3 * p + 2] = (double)(bx + d.off_x);
+  if (best == -INFINITY) status[p] = MISTITCH_PAIR_NO_CANDIDATE;
+}
+
+__global__ void k_ncc_single(const uint16_t* a, int64_t pa, const uint16_t* b, int64_t pb, int h, int w,
+                             unsigned long long* acc) {
+  __shared__ unsigned long long red[5 * kThreads / 64];
+  unsigned long long sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
+  for (int r = blockIdx.x; r < h; r += gridDim.x) {
+    for (int i = threadIdx.x; i < w; i += kThreads) {
+      const unsigned long long va = a[(int64_t)r * pa + i], vb = b[(int64_t)r * pb + i];
+      sa += va;
+      sb += vb;
+      saa += va * va;
+      sbb += vb * vb;
+      sab += va * vb;
+    }
+  }
+  unsigned long long v[5] = {sa, sb, saa, sbb, sab};
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) red[wave * 5 + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    unsigned long long t = 0;
+    for (int w2 = 0; w2 < kThreads / 64; ++w2) t += red[w2 * 5 + threadIdx.x];
+    atomicAdd(&acc[threadIdx.x], t);
+  }
+}
+
+__global__ void k_ncc_single_finish(const unsigned long long* acc, long long n, double* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    out[0] = n < 25 ? -INFINITY : ncc_from_moments((unsigned long long)n, acc[0], acc[1], acc[2], acc[3], acc[4]);
+}
+
+__global__ void k_peaks_to_arrays(const Peak* peaks, int k, int img_w, int32_t* rows, int32_t* cols,
+                                  double* vals) {
+  const int i = threadIdx.x;
+  if (i >= k) return;
+  const Peak pk = peaks[i];
+  rows[i] = pk.key / img_w;
+  cols[i] = pk.key - (pk.key / img_w) * img_w;
+  vals[i] = pk.val;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+static int build_plan(mistitch_ctx* ctx, int n, bool f64, FftPlanDev* out) {
+  const long long key = (long long)n * 2 + (f64 ? 1 : 0);
+  auto it = ctx->plans.find(key);
+  if (it != ctx->plans.end()) {
+    *out = it->second.dev;
+    return MISTITCH_OK;
+  }
+  FftPlanHost ph;
+  ph.dev.n = n;
+  // remainder radix first, then 16s: the last (largest) radix sets how many
+  // adjacent storage positions share their low frequency digits.
+  int lg = 0;
+  while ((1 << lg) < n) ++lg;
+  int np = 0;
+  if (lg % 4) ph.dev.radix[np++] = 1 << (lg % 4);
+  for (int i = 0; i < lg / 4; ++i) ph.dev.radix[np++] = 16;
+  ph.dev.npass = np;
+  {
+    long long prod = 1;
+    for (int i = 0; i < np; ++i) prod *= ph.dev.radix[i];
+    MS_REQUIRE(prod == n && np <= 6, MISTITCH_ERR_UNSUPPORTED, "cannot factor FFT length %d", n);
+    for (int i = 0; i < np; ++i)
+      MS_REQUIRE(ph.dev.radix[i] == 2 || ph.dev.radix[i] == 4 || ph.dev.radix[i] == 8 || ph.dev.radix[i] == 16,
+                 MISTITCH_ERR_UNSUPPORTED, "bad radix %d for FFT length %d", ph.dev.radix[i], n);
+  }
+  std::vector<uint16_t> pos2freq(n), freq2pos(n), mpos(n);
+  for (int pos = 0; pos < n; ++pos) {
+    int rest = pos, span = n, mult = 1, k = 0;
+    for (int i = 0; i < np; ++i) {
+      span /= ph.dev.radix[i];
+      const int digit = rest / span;
+      rest -= digit * span;
+      k += digit * mult;
+      mult *= ph.dev.radix[i];
+    }
+    pos2freq[pos] = (uint16_t)k;
+    freq2pos[k] = (uint16_t)pos;
+  }
+  for (int pos = 0; pos < n; ++pos) mpos[pos] = freq2pos[(n - pos2freq[pos]) % n];
+  const size_t esz = f64 ? 16 : 8;
+  const size_t tw_bytes = (size_t)n * esz;
+  const size_t tab_bytes = (size_t)n * sizeof(uint16_t);
+  const size_t tab_stride = (tab_bytes + 255) / 256 * 256;
+  const size_t total = (tw_bytes + 255) / 256 * 256 + 3 * tab_stride;
+  std::vector<char> host(total, 0);
+  for (int k = 0; k < n; ++k) {
+    const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+    const long double c = cosl(ang), s = sinl(ang);
+    if (f64) {
+      double* t = reinterpret_cast<double*>(host.data()) + 2 * k;
+      t[0] = (double)c;
+      t[1] = (double)s;
+    } else {
+      float* t = reinterpret_cast<float*>(host.data()) + 2 * k;
+      t[0] = (float)c;
+      t[1] = (float)s;
+    }
+  }
+  const size_t off0 = (tw_bytes + 255) / 256 * 256;
+  memcpy(host.data() + off0, pos2freq.data(), tab_bytes);
+  memcpy(host.data() + off0 + tab_stride, freq2pos.data(), tab_bytes);
+  memcpy(host.data() + off0 + 2 * tab_stride, mpos.data(), tab_bytes);
+  MS_HIP(hipMalloc(&ph.blob, total));
+  MS_HIP(hipMemcpy(ph.blob, host.data(), total, hipMemcpyHostToDevice));
+  char* base = reinterpret_cast<char*>(ph.blob);
+  ph.dev.tw = base;
+  ph.dev.pos2freq = reinterpret_cast<const uint16_t*>(base + off0);
+  ph.dev.freq2pos = reinterpret_cast<const uint16_t*>(base + off0 + tab_stride);
+  ph.dev.mpos = reinterpret_cast<const uint16_t*>(base + off0 + 2 * tab_stride);
+  ctx->plans[key] = ph;
+  *out = ph.dev;
+  return MISTITCH_OK;
+}
+
+// Largest block width C (power of two) such that the storage positions of the
+// negated frequencies of every aligned block of C positions form one aligned
+// block again, and the short-axis working set fits the LDS budget.
+static int choose_cps_block(const std::vector<uint16_t>& mpos, int L, int S, size_t esz, size_t lds_budget) {
+  int C = 16;
+  while (C > 1) {
+    bool ok = (C <= L) && ((size_t)S * 2 * C * esz <= lds_budget);
+    if (ok) {
+      for (int b = 0; b < L / C && ok; ++b) {
+        const int mb = mpos[b * C] / C;
+        for (int c = 1; c < C; ++c)
+          if (mpos[b * C + c] / C != mb) {
+            ok = false;
+            break;
+          }
+      }
+    }
+    if (ok) return C;
+    C >>= 1;
+  }
+  return 1;
+}
+
+struct ShapeCfg {
+  int S, L;
+  FftPlanDev planS, planL;
+  int C;       // columns per k_fft_short_cps block
+  int NF_fwd;  // lines per k_fft_long_fwd block
+  int NF_inv;  // line pairs per k_fft_long_inv block
+  size_t lds_fwd, lds_cps, lds_inv;
+};
+
+constexpr size_t kLdsBudget = 64 * 1024;  // two blocks per CU
+constexpr size_t kLdsMax = 160 * 1024;
+
+template <typename T>
+static size_t line_bytes(int L) {
+  return (size_t)(LineAddr<T>::padded(L) + 1) * sizeof(cx<T>);
+}
+
+static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) {
+  MS_REQUIRE(is_pow2(S) && is_pow2(L) && S >= 8 && L >= 8 && L <= 4096 && S <= 1024, MISTITCH_ERR_UNSUPPORTED,
+             "strip %d x %d unsupported: sides must be powers of two, long side in [8, 4096], short side in [8, 1024]",
+             S, L);
+  cfg->S = S;
+  cfg->L = L;
+  int rc = build_plan(ctx, S, f64, &cfg->planS);
+  if (rc) return rc;
+  rc = build_plan(ctx, L, f64, &cfg->planL);
+  if (rc) return rc;
+  const size_t esz = f64 ? 16 : 8;
+  std::vector<uint16_t> mpos(L);
+  MS_HIP(hipMemcpy(mpos.data(), cfg->planL.mpos, (size_t)L * 2, hipMemcpyDeviceToHost));
+  cfg->C = choose_cps_block(mpos, L, S, esz, kLdsBudget);
+  cfg->lds_cps = (size_t)S * 2 * cfg->C * esz;
+  MS_REQUIRE(cfg->lds_cps <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "short side %d needs %zu B of LDS", S, cfg->lds_cps);
+  const size_t lb = f64 ? line_bytes<double>(L) : line_bytes<float>(L);
+  int nf = (int)(kLdsBudget / lb);
+  if (nf < 1) nf = 1;
+  int want = kThreads * 16 / L;  // enough butterflies to occupy every lane
+  if (want < 1) want = 1;
+  if (nf > want) nf = want;
+  while (nf & (nf - 1)) nf &= nf - 1;  // round down to a power of two
+  cfg->NF_fwd = nf > S ? S : nf;
+  cfg->NF_inv = nf > S / 2 ? S / 2 : nf;
+  cfg->lds_fwd = lb * cfg->NF_fwd;
+  cfg->lds_inv = lb * cfg->NF_inv;
+  MS_REQUIRE(cfg->lds_fwd <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "long side %d needs %zu B of LDS", L, cfg->lds_fwd);
+  return MISTITCH_OK;
+}
+
+template <typename KernelT>
+static int allow_lds(KernelT kernel, size_t bytes) {
+  if (bytes > 48 * 1024)
+    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)bytes));
+  return MISTITCH_OK;
+}
+
+struct RegWorkspace {
+  PairDesc* desc;
+  uint16_t* staging;
+  void* spectrum;
+  Peak* partial;
+  Peak* peaks;
+  Cand* cand;
+  unsigned long long* acc;
+  int partial_stride;
+};
+
+static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, size_t staging_elems_per_pair,
+                                size_t spectrum_bytes_per_pair, int partial_stride, RegWorkspace* ws) {
+  int rc;
+  if ((rc = ctx->desc.reserve((size_t)n_pairs * sizeof(PairDesc)))) return rc;
+  if ((rc = ctx->staging.reserve((size_t)chunk * staging_elems_per_pair * 2 + 256))) return rc;
+  if ((rc = ctx->spectrum.reserve((size_t)chunk * spectrum_bytes_per_pair))) return rc;
+  if ((rc = ctx->partial.reserve((size_t)chunk * partial_stride * sizeof(Peak)))) return rc;
+  if ((rc = ctx->peaks.reserve((size_t)n_pairs * kMaxK * sizeof(Peak)))) return rc;
+  if ((rc = ctx->cand.reserve((size_t)n_pairs * kNumCand * sizeof(Cand)))) return rc;
+  if ((rc = ctx->acc.reserve((size_t)n_pairs * kNumCand * 5 * sizeof(unsigned long long)))) return rc;
+  ws->desc = (PairDesc*)ctx->desc.ptr;
+  ws->staging = (uint16_t*)ctx->staging.ptr;
+  ws->spectrum = ctx->spectrum.ptr;
+  ws->partial = (Peak*)ctx->partial.ptr;
+  ws->peaks = (Peak*)ctx->peaks.ptr;
+  ws->cand = (Cand*)ctx->cand.ptr;
+  ws->acc = (unsigned long long*)ctx->acc.ptr;
+  ws->partial_stride = partial_stride;
+  return MISTITCH_OK;
+}
+
+// The three FFT kernels for pairs [pair0, pair0 + n) of one canonical shape.
+template <typename T>
+static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace& ws, const int8_t* status,
+                      int pair0, int n, int want_transposed, bool vec_ok, int k, double* pcm_out) {
+  hipStream_t st = ctx->stream;
+  cx<T>* spec = reinterpret_cast<cx<T>*>(ws.spectrum);
+  int rc;
+  if (vec_ok) {
+    if ((rc = allow_lds(k_fft_long_fwd<T, true>, cfg.lds_fwd))) return rc;
+    hipLaunchKernelGGL((k_fft_long_fwd<T, true>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd, st,
+                       ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, spec);
+  } else {
+    if ((rc = allow_lds(k_fft_long_fwd<T, false>, cfg.lds_fwd))) return rc;
+    hipLaunchKernelGGL((k_fft_long_fwd<T, false>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd, st,
+                       ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, spec);
+  }
+  if ((rc = allow_lds(k_fft_short_cps<T>, cfg.lds_cps))) return rc;
+  const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
+  hipLaunchKernelGGL((k_fft_short_cps<T>), dim3(cfg.L / cfg.C, n), dim3(kThreads), cfg.lds_cps, st, ws.desc, status,
+                     pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.C, spec, eps);
+  if ((rc = allow_lds(k_fft_long_inv<T>, cfg.lds_inv))) return rc;
+  hipLaunchKernelGGL((k_fft_long_inv<T>), dim3(cfg.S / (2 * cfg.NF_inv), n), dim3(kThreads), cfg.lds_inv, st, ws.desc,
+                     status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.C, cfg.NF_inv, spec, k, ws.partial,
+                     ws.partial_stride, pcm_out);
+  MS_HIP(hipGetLastError());
+  return MISTITCH_OK;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace mistitch
+
+using namespace mistitch;
+
+extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int edge_width,
+                                             int max_pairs, unsigned flags) {
+  MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
+  MS_REQUIRE(tile_h > 0 && tile_w > 0 && edge_width > 0 && max_pairs > 0, MISTITCH_ERR_ARG, "non-positive size");
+  MS_HIP(hipSetDevice(ctx->device));
+  const bool f64 = !(flags & MISTITCH_FFT_F32);
+  const int w_left = edge_width < tile_w ? edge_width : tile_w;
+  const int w_top = edge_width < tile_h ? edge_width : tile_h;
+  ShapeCfg a, b;
+  int rc;
+  if ((rc = make_shape(ctx, w_left, tile_h, f64, &a))) return rc;
+  if ((rc = make_shape(ctx, w_top, tile_w, f64, &b))) return rc;
+  const size_t esz = f64 ? 16 : 8;
+  const size_t spec = std::max((size_t)a.S * a.L, (size_t)b.S * b.L) * esz;
+  const int pstride = std::max(a.S / (2 * a.NF_inv), b.S / (2 * b.NF_inv)) * kMaxK;
+  const int chunk = max_pairs < ctx->pair_chunk ? max_pairs : ctx->pair_chunk;
+  RegWorkspace ws;
+  return reserve_registration(ctx, max_pairs, chunk, (size_t)w_left * tile_h * 2, spec, pstride, &ws);
+}
+
+extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h,
+                                       int tile_w, int64_t tile_pitch, const int32_t* pair_idx,
+                                       const uint8_t* pair_dir, int n_pairs, int edge_width, unsigned flags,
+                                       double* out, int8_t* status) {
+  MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
+  MS_REQUIRE(n_pairs >= 0 && n_tiles >= 0, MISTITCH_ERR_ARG, "negative count");
+  if (n_pairs == 0) return MISTITCH_OK;
+  MS_REQUIRE(tiles && pair_idx && pair_dir && out && status, MISTITCH_ERR_ARG, "NULL array argument");
+  MS_REQUIRE(tile_h > 0 && tile_w > 0 && edge_width > 0, MISTITCH_ERR_ARG, "non-positive size");
+  MS_REQUIRE(tile_pitch >= (int64_t)tile_h * tile_w, MISTITCH_ERR_ARG, "tile_pitch smaller than a tile");
+  MS_HIP(hipSetDevice(ctx->device));
+  const bool f64 = !(flags & MISTITCH_FFT_F32);
+  const int H = tile_h, W = tile_w;
+  const int w_left = edge_width < W ? edge_width : W;
+  const int w_top = edge_width < H ? edge_width : H;
+  ShapeCfg cfg_left, cfg_top;
+  int rc;
+  if ((rc = make_shape(ctx, w_left, H, f64, &cfg_left))) return rc;
+  if ((rc = make_shape(ctx, w_top, W, f64, &cfg_top))) return rc;
+  const bool same_shape = cfg_left.S == cfg_top.S && cfg_left.L == cfg_top.L;
+  const size_t esz = f64 ? 16 : 8;
+  const size_t spec = std::max((size_t)cfg_left.S * cfg_left.L, (size_t)cfg_top.S * cfg_top.L) * esz;
+  const int pstride = std::max(cfg_left.S / (2 * cfg_left.NF_inv), cfg_top.S / (2 * cfg_top.NF_inv)) * kMaxK;
+  const int chunk = n_pairs < ctx->pair_chunk ? n_pairs : ctx->pair_chunk;
+  RegWorkspace ws;
+  if ((rc = reserve_registration(ctx, n_pairs, chunk, (size_t)w_left * H * 2, spec, pstride, &ws))) return rc;
+  hipStream_t st = ctx->stream;
+  // 16-byte loads of tile rows need aligned rows; staging lines always are.
+  const bool vec_top = aligned16(tiles) && (W % 8 == 0) && (tile_pitch % 8 == 0);
+  const int k = 2;  // peaks the candidate search consumes
+
+  hipLaunchKernelGGL(k_setup_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, st, tiles, tile_pitch, H, W, w_left,
+                     w_top, pair_idx, pair_dir, n_pairs, n_tiles, ws.staging, chunk, ws.desc, status);
+  hipLaunchKernelGGL(k_edge_stats, dim3(2, n_pairs), dim3(kThreads), 0, st, tiles, tile_pitch, H, W, w_left, w_top,
+                     pair_idx, pair_dir, status, 2e3);
+  for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {
+    const int n = std::min(chunk, n_pairs - pair0);
+    hipLaunchKernelGGL(k_transpose_strips, dim3((H + 31) / 32, (w_left + 31) / 32, 2 * n), dim3(32, 8), 0, st, tiles,
+                       tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
+    if (same_shape) {
+      // left strips come from the aligned staging buffer, top strips from the tiles
+      rc = f64 ? launch_fft<double>(ctx, cfg_left, ws, status, pair0, n, -1, vec_top, k, nullptr)
+               : launch_fft<float>(ctx, cfg_left, ws, status, pair0, n, -1, vec_top, k, nullptr);
+      if (rc) return rc;
+    } else {
+      rc = f64 ? launch_fft<double>(ctx, cfg_left, ws, status, pair0, n, 1, true, k, nullptr)
+               : launch_fft<float>(ctx, cfg_left, ws, status, pair0, n, 1, true, k, nullptr);
+      if (rc) return rc;
+      rc = f64 ? launch_fft<double>(ctx, cfg_top, ws, status, pair0, n, 0, vec_top, k, nullptr)
+               : launch_fft<float>(ctx, cfg_top, ws, status, pair0, n, 0, vec_top, k, nullptr);
+      if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_peaks_candidates, dim3(n), dim3(kThreads), 0, st, ws.desc, status, pair0, ws.partial,
+                       ws.partial_stride, cfg_top.S / (2 * cfg_top.NF_inv), cfg_left.S / (2 * cfg_left.NF_inv), k, 2,
+                       ws.peaks, ws.cand, ws.acc);
+    hipLaunchKernelGGL(k_ncc_accumulate, dim3(kNccChunks, kNumCand, n), dim3(kThreads), 0, st, ws.desc, status, pair0,
+                       ws.cand, ws.acc);
+  }
+  hipLaunchKernelGGL(k_finalize, dim3((n_pairs + 63) / 64), dim3(64), 0, st, ws.desc, status, n_pairs, ws.cand, ws.acc,
+                     out, status);
+  MS_HIP(hipGetLastError());
+  return MISTITCH_OK;
+}
+
+// Shared body of mistitch_pcm / mistitch_pcm_topk: one pair of free-standing strips.
+static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1, const uint16_t* strip2,
+                           int64_t pitch2, int h, int w, unsigned flags, int k, double* out_pcm, int32_t* rows,
+                           int32_t* cols, double* vals) {
+  MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
+  MS_REQUIRE(strip1 && strip2, MISTITCH_ERR_ARG, "NULL strip");
+  MS_REQUIRE(h > 0 && w > 0 && pitch1 >= w && pitch2 >= w, MISTITCH_ERR_ARG, "bad strip geometry");
+  MS_REQUIRE(k >= 0 && k <= kMaxK, MISTITCH_ERR_ARG, "k must be in [0, %d]", kMaxK);
+  MS_HIP(hipSetDevice(ctx->device));
+  const bool f64 = !(flags & MISTITCH_FFT_F32);
+  const bool transposed = h > w;  // tall strips are processed transposed
+  const int S = transposed ? w : h, L = transposed ? h : w;
+  ShapeCfg cfg;
+  int rc;
+  if ((rc = make_shape(ctx, S, L, f64, &cfg))) return rc;
+  const size_t esz = f64 ? 16 : 8;
+  const int pstride = (cfg.S / (2 * cfg.NF_inv)) * kMaxK;
+  RegWorkspace ws;
+  if ((rc = reserve_registration(ctx, 1, 1, (size_t)S * L, (size_t)S * L * esz, pstride, &ws))) return rc;
+  if ((rc = ctx->misc.reserve(256))) return rc;
+  hipStream_t st = ctx->stream;
+  PairDesc d;
+  bool vec = true;
+  if (transposed) {
+    hipLaunchKernelGGL(k_transpose_plain, dim3((h + 31) / 32, (w + 31) / 32), dim3(32, 8), 0, st, strip1, pitch1, h, w,
+                       ws.staging);
+    hipLaunchKernelGGL(k_transpose_plain, dim3((h + 31) / 32, (w + 31) / 32), dim3(32, 8), 0, st, strip2, pitch2, h, w,
+                       ws.staging + (size_t)S * L);
+    d.a = ws.staging;
+    d.b = ws.staging + (size_t)S * L;
+    d.pitch = L;
+  } else {
+    // the kernels share one pitch per pair; a strip with another pitch is staged
+    d.a = strip1;
+    d.b = strip2;
+    d.pitch = pitch1;
+    if (pitch2 != pitch1) {
+      MS_HIP(hipMemcpy2DAsync(ws.staging, (size_t)L * 2, strip1, (size_t)pitch1 * 2, (size_t)L * 2, S,
+                              hipMemcpyDeviceToDevice, st));
+      MS_HIP(hipMemcpy2DAsync(ws.staging + (size_t)S * L, (size_t)L * 2, strip2, (size_t)pitch2 * 2, (size_t)L * 2, S,
+                              hipMemcpyDeviceToDevice, st));
+      d.a = ws.staging;
+      d.b = ws.staging + (size_t)S * L;
+      d.pitch = L;
+    }
+    vec = aligned16(d.a) && aligned16(d.b) && (d.pitch % 8 == 0);
+  }
+  d.S = S;
+  d.L = L;
+  d.transposed = transposed ? 1 : 0;
+  d.img_h = h;
+  d.img_w = w;
+  d.off_y = d.off_x = 0;
+  int8_t* status = reinterpret_cast<int8_t*>(ctx->misc.ptr);
+  MS_HIP(hipMemsetAsync(status, 0, 16, st));
+  MS_HIP(hipMemcpyAsync(ws.desc, &d, sizeof(d), hipMemcpyHostToDevice, st));
+  MS_HIP(hipStreamSynchronize(st));  // d lives on this stack frame
+  rc = f64 ? launch_fft<double>(ctx, cfg, ws, status, 0, 1, -1, vec, k, out_pcm)
+           : launch_fft<float>(ctx, cfg, ws, status, 0, 1, -1, vec, k, out_pcm);
+  if (rc) return rc;
+  if (k > 0) {
+    hipLaunchKernelGGL(k_peaks_candidates, dim3(1), dim3(kThreads), 0, st, ws.desc, status, 0, ws.partial,
+                       ws.partial_stride, cfg.S / (2 * cfg.NF_inv), cfg.S / (2 * cfg.NF_inv), k, 0, ws.peaks,
+                       (Cand*)nullptr, (unsigned long long*)nullptr);
+    hipLaunchKernelGGL(k_peaks_to_arrays, dim3(1), dim3(64), 0, st, ws.peaks, k, w, rows, cols, vals);
+  }
+  MS_HIP(hipGetLastError());
+  return MISTITCH_OK;
+}
+
+extern "C" int mistitch_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1, const uint16_t* strip2,
+                            int64_t pitch2, int h, int w, unsigned flags, double* out_pcm) {
+  MS_REQUIRE(out_pcm, MISTITCH_ERR_ARG, "out_pcm is NULL");
+  return single_pair_pcm(ctx, strip1, pitch1, strip2, pitch2, h, w, flags, 0, out_pcm, nullptr, nullptr, nullptr);
+}
+
+extern "C" int mistitch_pcm_topk(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1, const uint16_t* strip2,
+                                 int64_t pitch2, int h, int w, unsigned flags, int k, int32_t* rows, int32_t* cols,
+                                 double* vals) {
+  MS_REQUIRE(rows && cols && vals, MISTITCH_ERR_ARG, "NULL output array");
+  MS_REQUIRE(k >= 1 && k <= kMaxK, MISTITCH_ERR_ARG, "k must be in [1, %d]", kMaxK);
+  return single_pair_pcm(ctx, strip1, pitch1, strip2, pitch2, h, w, flags, k, nullptr, rows, cols, vals);
+}
+
+extern "C" int mistitch_ncc(mistitch_ctx* ctx, const uint16_t* patch1, int64_t pitch1, const uint16_t* patch2,
+                            int64_t pitch2, int h, int w, double* out) {
+  MS_REQUIRE(ctx && out, MISTITCH_ERR_ARG, "NULL argument");
+  MS_REQUIRE(h >= 0 && w >= 0, MISTITCH_ERR_ARG, "negative size");
+  MS_REQUIRE((patch1 && patch2) || h * (long long)w == 0, MISTITCH_ERR_ARG, "NULL patch");
+  MS_REQUIRE((long long)h * w <= (1ll << 30), MISTITCH_ERR_UNSUPPORTED, "patch larger than 2^30 pixels");
+  MS_HIP(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = ctx->misc.reserve(256))) return rc;
+  hipStream_t st = ctx->stream;
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->misc.ptr) + 64);
+  MS_HIP(hipMemsetAsync(acc, 0, 5 * sizeof(unsigned long long), st));
+  if ((long long)h * w > 0)
+    hipLaunchKernelGGL(k_ncc_single, dim3(h < 1024 ? h : 1024), dim3(kThreads), 0, st, patch1, pitch1, patch2, pitch2,
+                       h, w, acc);
+  hipLaunchKernelGGL(k_ncc_single_finish, dim3(1), dim3(64), 0, st, acc, (long long)h * w, out);
+  MS_HIP(hipGetLastError());
+  return MISTITCH_OK;
+}
+
+extern "C" int mistitch_edge_variance(mistitch_ctx* ctx, const uint16_t* strip, int64_t pitch, int h, int w,
+                                      double* out_var) {
+  MS_REQUIRE(ctx && strip && out_var, MISTITCH_ERR_ARG, "NULL argument");
+  MS_REQUIRE(h > 0 && w > 0 && pitch >= w, MISTITCH_ERR_ARG, "bad strip geometry");
+  MS_HIP(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_variance_single, dim3(1), dim3(kThreads), 0, ctx->stream, strip, pitch, h, w, out_var);
+  MS_HIP(hipGetLastError());
+  return MISTITCH_OK;
+}

@@ -1,0 +1,163 @@
+/* libmistitch: C ABI of the MI355X (gfx950) registration-and-fusion hot path.
+ *
+ * The reference (maragall/image-stitcher) is pure Python and has no FFI of its
+ * own; the seam this library slots under is the set of Python functions cited
+ * beside each entry point (paths relative to the reference checkout).  A
+ * ctypes binding calls these functions with device pointers obtained from
+ * torch tensors (`tensor.data_ptr()`).
+ *
+ * Conventions
+ *   - every array argument is a DEVICE pointer unless the comment says host;
+ *   - the library never frees or retains caller memory; it owns only the
+ *     context's plans and workspaces;
+ *   - work is enqueued on the context's stream and is asynchronous with
+ *     respect to the host unless stated otherwise;
+ *   - every function returns MISTITCH_OK (0) or a negative error code, and
+ *     mistitch_last_error() then describes the failure (per calling thread);
+ *   - one call at a time per context; different contexts are independent.
+ */
+#ifndef MISTITCH_H
+#define MISTITCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISTITCH_OK 0
+#define MISTITCH_ERR_ARG (-1)         /* invalid argument (NULL, negative size, bad enum) */
+#define MISTITCH_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for     */
+#define MISTITCH_ERR_HIP (-3)         /* a HIP runtime call failed                        */
+#define MISTITCH_ERR_NOMEM (-4)       /* device allocation failed                         */
+
+/* per-pair status written by mistitch_register_pairs */
+#define MISTITCH_PAIR_OK 0
+#define MISTITCH_PAIR_FEATURELESS 1  /* a strip failed the variance test: reference returns None */
+#define MISTITCH_PAIR_NO_CANDIDATE 2 /* no candidate scored: row holds (-inf, off_y, off_x)      */
+
+/* flags */
+#define MISTITCH_FFT_F64 0u /* complex128 spectra, as the reference computes them (default) */
+#define MISTITCH_FFT_F32 1u /* complex64 spectra: half the traffic, PCM differs at ~1e-7     */
+
+/* fusion modes */
+#define MISTITCH_FUSE_OVERWRITE 0 /* last writer wins, the reference behaviour */
+#define MISTITCH_FUSE_FEATHER 1   /* separable linear-ramp weighted mean (no reference counterpart) */
+
+/* flatfield element types */
+#define MISTITCH_FF_NONE 0
+#define MISTITCH_FF_F32 1
+#define MISTITCH_FF_F64 2
+
+typedef struct mistitch_ctx mistitch_ctx;
+
+int mistitch_version(void);
+
+/* Message for the most recent error on the calling thread ("" if none). */
+const char* mistitch_last_error(void);
+
+/* Create a context on `device`.  `stream` is a hipStream_t (NULL = the legacy
+ * default stream).  Replaces the reference's global backend singleton
+ * (image_stitcher/registration/tile_registration.py:72-97) for this path. */
+int mistitch_create(int device, void* stream, mistitch_ctx** out);
+int mistitch_destroy(mistitch_ctx* ctx);
+
+/* Pairs are processed in passes of `pairs_per_pass` (>=1) to bound the FFT
+ * workspace (and keep it cache resident).  Default 32. */
+int mistitch_set_pair_chunk(mistitch_ctx* ctx, int pairs_per_pass);
+
+/* Pre-size all workspaces so that later mistitch_register_pairs calls with
+ * shapes up to these do not allocate. */
+int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int edge_width,
+                                  int max_pairs, unsigned flags);
+
+/* Pairwise registration of neighbouring tiles.
+ * Replaces the serial pair loop of process_neighborhood_batch
+ * (tile_registration.py:310-378) and, per pair, compute_single_translation
+ * (tile_registration.py:527-586): featureless test, phase correlation, peak
+ * ranking, 16-candidate NCC search over the two best peaks.
+ *
+ *   tiles      [n_tiles] images of tile_h x tile_w uint16, row-major, image t at
+ *              tiles + t * tile_pitch (elements)
+ *   pair_idx   [n_pairs][2] int32: (first, second); second is the right ("left"
+ *              pair, dir 0) or lower ("top" pair, dir 1) neighbour
+ *   pair_dir   [n_pairs] uint8: 0 = left, 1 = top
+ *   out        [n_pairs][3] float64: ncc, y, x of the second tile's origin in
+ *              the first tile's frame; NaN row when status is FEATURELESS
+ *   status     [n_pairs] int8: MISTITCH_PAIR_*
+ *
+ * Strip sides must be powers of two within [8, 4096] (long) / [8, 1024] (short).
+ */
+int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h,
+                            int tile_w, int64_t tile_pitch, const int32_t* pair_idx,
+                            const uint8_t* pair_dir, int n_pairs, int edge_width, unsigned flags,
+                            double* out, int8_t* status);
+
+/* Peak correlation matrix of two equal-shape uint16 strips.
+ * Replaces pcm() (registration/_translation_computation.py:282-340).
+ *   strip1/2   h x w uint16 with row pitches pitch1/pitch2 (elements)
+ *   out_pcm    [h][w] float64 (always float64, whatever the FFT precision)     */
+int mistitch_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1, const uint16_t* strip2,
+                 int64_t pitch2, int h, int w, unsigned flags, double* out_pcm);
+
+/* The k (1..16) largest PCM entries of two strips in descending order; equal
+ * values are ordered by descending flat index.  Replaces
+ * multi_peak_max(pcm(a, b), max_peaks=k) (_translation_computation.py:342-441).
+ *   rows, cols [k] int32;  vals [k] float64                                     */
+int mistitch_pcm_topk(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1,
+                      const uint16_t* strip2, int64_t pitch2, int h, int w, unsigned flags, int k,
+                      int32_t* rows, int32_t* cols, double* vals);
+
+/* Pearson correlation of two h x w uint16 patches, exact integer moments.
+ * Replaces ncc() (_translation_computation.py:535-616); -inf when h*w < 25.
+ *   out        [1] float64                                                      */
+int mistitch_ncc(mistitch_ctx* ctx, const uint16_t* patch1, int64_t pitch1, const uint16_t* patch2,
+                 int64_t pitch2, int h, int w, double* out);
+
+/* The strip variance test of is_edge_featureless (tile_registration.py:497-525):
+ * population variance of every 16th sample in both directions.
+ *   out_var    [1] float64                                                      */
+int mistitch_edge_variance(mistitch_ctx* ctx, const uint16_t* strip, int64_t pitch, int h, int w,
+                           double* out_var);
+
+/* out = trunc(clip(in / flatfield, 0, 65535)) per pixel, n_tiles images sharing
+ * one flatfield plane.  Replaces apply_flatfield_to_image
+ * (tile_registration.py:2142-2181) and Stitcher.apply_flatfield_correction
+ * (stitcher.py:255-270).  ff_type: MISTITCH_FF_F32 or MISTITCH_FF_F64.
+ * in and out may alias.                                                         */
+int mistitch_apply_flatfield(mistitch_ctx* ctx, const uint16_t* in, const void* flatfield,
+                             int ff_type, uint16_t* out, int n_tiles, int tile_h, int tile_w);
+
+/* Fuse tiles into a mosaic.  Replaces the tile loop of Stitcher.stitch_region
+ * (stitcher.py:388-405) with place_tile / place_single_channel_tile
+ * (stitcher.py:208-253, 272-311).
+ *
+ *   tiles      [n_tiles] images tile_h x tile_w uint16, image t at tiles + t*tile_pitch
+ *   tile_yx    [n_tiles][2] int32 mosaic position (y, x) of each tile's origin, >= 0
+ *   tile_plane [n_tiles] int32 destination plane (channel * Z + z) of each tile
+ *   n_planes   planes in the mosaic; planes are mosaic_h x mosaic_w, contiguous
+ *   tile array order IS the placement order: a later tile overwrites an earlier one
+ *   flatfields [n_ff_planes] planes tile_h x tile_w (ff_type), or NULL
+ *   tile_ff    [n_tiles] int32 flatfield plane per tile (-1 = none), or NULL
+ *   mosaic     [n_planes][mosaic_h][mosaic_w] uint16, fully written for rows
+ *              [row0, row1) of every plane (uncovered pixels = 0)
+ *   mode       MISTITCH_FUSE_OVERWRITE | MISTITCH_FUSE_FEATHER
+ */
+int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
+                  int64_t tile_pitch, const int32_t* tile_yx, const int32_t* tile_plane,
+                  const void* flatfields, int ff_type, const int32_t* tile_ff, uint16_t* mosaic,
+                  int n_planes, int mosaic_h, int mosaic_w, int row0, int row1, int mode);
+
+/* Per-pixel maximum over `n` images of h*w uint16 (image i at in + i*pitch).
+ * Replaces Stitcher.compute_mip (stitcher.py:102-121).                           */
+int mistitch_mip(mistitch_ctx* ctx, const uint16_t* in, int n, int64_t pitch, int64_t n_pixels,
+                 uint16_t* out);
+
+/* Block the calling thread until the context's stream has drained. */
+int mistitch_synchronize(mistitch_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISTITCH_H */

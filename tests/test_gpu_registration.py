@@ -1,0 +1,166 @@
+"""HIP registration path against the oracle and the reference's golden vectors (needs an MI355X)."""
+import numpy as np
+import pytest
+
+from image_stitcher_amd import synth
+from oracle import registration as oreg
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def reg():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from image_stitcher_amd import registration
+    return registration
+
+
+def _grid(spec):
+    return synth.make_grid(spec["seed"], spec["rows"], spec["cols"], spec["tile_h"], spec["tile_w"],
+                           overlap=spec["overlap"], jitter=spec["jitter"])
+
+
+def _pow2(n):
+    return n & (n - 1) == 0
+
+
+def _supported(spec):
+    return all(_pow2(v) for v in (spec["tile_h"], spec["tile_w"], min(spec["edge_width"], spec["tile_h"]),
+                                  min(spec["edge_width"], spec["tile_w"])))
+
+
+@pytest.mark.parametrize("fft", ["f64", "f32"])
+def test_grids_match_reference_golden(reg, golden, fft):
+    for spec in golden["grids"]:
+        if not _supported(spec):
+            continue
+        g = _grid(spec)
+        out, status = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, spec["edge_width"], fft=fft)
+        out, status = out.cpu().numpy(), status.cpu().numpy()
+        assert (status == 0).all(), spec["name"]
+        exp = np.array(spec["results"], dtype=np.float64)
+        # integer shifts: bit exact; NCC: 1e-12
+        assert np.array_equal(out[:, 1:], exp[:, 1:]), spec["name"]
+        assert np.allclose(out[:, 0], exp[:, 0], rtol=0, atol=1e-12), spec["name"]
+        assert np.array_equal(out[:, 1:].astype(np.int64), g.expected_shift)
+
+
+def test_unsupported_shape_is_an_error(reg, golden):
+    spec = [s for s in golden["grids"] if not _supported(s)][0]
+    g = _grid(spec)
+    with pytest.raises(Exception):
+        reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, spec["edge_width"])
+
+
+def test_matches_oracle_on_fresh_seeds(reg):
+    for seed, (rows, cols, th, tw, ew) in enumerate([(3, 4, 256, 256, 32), (2, 5, 128, 512, 64), (4, 2, 512, 128, 64)]):
+        g = synth.make_grid(100 + seed, rows, cols, th, tw, overlap=0.15, jitter=4)
+        ref, ref_status = oreg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, ew, polish=False)
+        out, status = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, ew)
+        out, status = out.cpu().numpy(), status.cpu().numpy()
+        assert np.array_equal(status != 0, ref_status != 0)
+        assert np.array_equal(out[:, 1:], ref[:, 1:])
+        assert np.allclose(out[:, 0], ref[:, 0], rtol=0, atol=1e-12)
+
+
+def test_featureless_pairs(reg, golden):
+    f = golden["featureless"]
+    rng = np.random.default_rng(f["rng_seed"])
+    flat = (5000 + 20 * rng.random((512, 512))).astype(np.uint16)
+    tex = synth.make_scene(22, 512, 512)
+    tiles = np.stack([flat, tex])
+    # pairs: (flat, tex), (tex, flat), (tex, tex)
+    out, status = reg.register_pairs(tiles, [[0, 1], [1, 0], [1, 1]], [0, 0, 0], 64)
+    out, status = out.cpu().numpy(), status.cpu().numpy()
+    assert status[0] == 1 and status[1] == 1 and status[2] == 0
+    assert np.isnan(out[0]).all() and np.isnan(out[1]).all()
+    exp = f["pairs"]["both_textured"]
+    assert out[2, 1] == exp[1] and out[2, 2] == exp[2]
+    assert out[2, 0] == pytest.approx(exp[0], abs=1e-12)
+    # mirror of the per-pair function: None for rejected pairs
+    assert reg.compute_single_translation(flat, tex, "left", 512, 512, 64) is None
+    r = reg.compute_single_translation(tex, tex, "left", 512, 512, 64)
+    assert r[1:] == (exp[1], exp[2])
+    for probe in f["probes"]:
+        t = (5000 + probe["amp"] * rng.random((512, 64))).astype(np.uint16)
+        assert reg.is_edge_featureless(t) == probe["featureless"]
+        assert reg.edge_variance(t) == pytest.approx(probe["var_f32"], rel=1e-5)
+
+
+def test_pcm_and_peak_ranking(reg, golden):
+    for s in golden["peaks"]["strips"]:
+        h, w = s["shape"]
+        big = synth.make_scene(s["seed"], h + 64, w + 64)
+        a = np.ascontiguousarray(big[32:32 + h, 32:32 + w])
+        b = np.ascontiguousarray(big[32 + s["shift"][0]:32 + s["shift"][0] + h, 32 + s["shift"][1]:32 + s["shift"][1] + w])
+        ref = oreg.pcm(a, b)
+        got = reg.pcm(a, b)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 1e-12
+        assert float(got.sum()) == pytest.approx(s["pcm_sum"], rel=1e-9)
+        rows, cols, vals = reg.pcm_topk(a, b, 16)
+        for i, (er, ec, ev) in enumerate(s["top"]):
+            assert (rows[i], cols[i]) == (er, ec), (s["seed"], i)
+            assert vals[i] == pytest.approx(ev, rel=1e-9, abs=1e-13)
+        got32 = reg.pcm(a, b, fft="f32")
+        assert np.abs(got32 - ref).max() < 1e-5
+
+
+def test_ncc_table(reg, golden):
+    n = golden["ncc"]
+    rng = np.random.default_rng(n["seed"])
+    a = rng.integers(0, 65535, size=tuple(n["shape"])).astype(np.uint16)
+    b = rng.integers(0, 65535, size=tuple(n["shape"])).astype(np.uint16)
+    const = np.full(tuple(n["shape"]), 1234, dtype=np.uint16)
+    got = {
+        "random": reg.ncc(a, b), "self": reg.ncc(a, a),
+        "negated": reg.ncc(a, (65535 - a).astype(np.uint16)),
+        "size_24": reg.ncc(a[:4, :6], b[:4, :6]), "size_25": reg.ncc(a[:5, :5], b[:5, :5]),
+        "both_constant": reg.ncc(const, const), "one_constant": reg.ncc(a, const),
+        "shape_mismatch": reg.ncc(a, b[:, :29]), "empty": reg.ncc(a[:0], b[:0]),
+    }
+    for k, exp in n["values"].items():
+        if isinstance(exp, str):
+            assert got[k] == float(exp), k
+        else:
+            assert got[k] == pytest.approx(exp, abs=1e-13), k
+
+
+def test_candidate_winner(reg, golden):
+    for s in golden["candidates"]:
+        h, w = s["shape"]
+        dy, dx = s["shift"]
+        big = synth.make_scene(s["seed"], h + 64, w + 64)
+        a = np.ascontiguousarray(big[32:32 + h, 32:32 + w])
+        b = np.ascontiguousarray(big[32 + dy:32 + dy + h, 32 + dx:32 + dx + w])
+        rows, cols, _ = reg.pcm_topk(a, b, 2)
+        assert [[int(rows[0]), int(cols[0])], [int(rows[1]), int(cols[1])]] == s["peaks"]
+
+
+def test_process_neighborhood_batch_mirror(reg, golden):
+    spec = golden["grids"][0]
+    g = _grid(spec)
+
+    class P:  # stands in for pathlib.Path: only .name is used
+        def __init__(self, name):
+            self.name = name
+
+    paths = [P(f"t{i}.tiff") for i in range(len(g.tiles))]
+    images = {p.name: g.tiles[i] for i, p in enumerate(paths)}
+    hoods = []
+    for r in range(g.rows):
+        for c in range(g.cols):
+            t = r * g.cols + c
+            if c > 0 or r > 0:
+                hoods.append(reg.Neighborhood(t, t - 1 if c > 0 else None, t - g.cols if r > 0 else None))
+    res = reg.process_neighborhood_batch(hoods, images, list(range(len(paths))), paths, [p.name for p in paths],
+                                         None, spec["edge_width"])
+    exp = oreg.neighborhood_results(g.pair_idx, g.pair_dir, np.array(spec["results"]),
+                                    np.zeros(len(g.pair_idx), dtype=np.int8))
+    assert res.keys() == exp.keys()
+    for k in exp:
+        assert res[k].keys() == exp[k].keys()
+        for d in exp[k]:
+            assert res[k][d]["y"] == exp[k][d]["y"] and res[k][d]["x"] == exp[k][d]["x"]
+            assert res[k][d]["ncc"] == pytest.approx(exp[k][d]["ncc"], abs=1e-12)

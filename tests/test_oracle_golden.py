@@ -60,8 +60,10 @@ def test_featureless(golden):
 
 def test_peak_ranking(golden):
     for s in golden["peaks"]["strips"]:
-        a = synth.make_scene(s["seed"], *s["shape"])
-        b = np.roll(a, tuple(s["roll"]), axis=(0, 1))
+        h, w = s["shape"]
+        big = synth.make_scene(s["seed"], h + 64, w + 64)
+        a = np.ascontiguousarray(big[32:32 + h, 32:32 + w])
+        b = np.ascontiguousarray(big[32 + s["shift"][0]:32 + s["shift"][0] + h, 32 + s["shift"][1]:32 + s["shift"][1] + w])
         p = oreg.pcm(a, b)
         assert float(p.sum()) == pytest.approx(s["pcm_sum"], rel=1e-12)
         r, c, v = oreg.multi_peak_max(p, max_peaks=16)
