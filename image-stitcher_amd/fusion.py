@@ -1,0 +1,208 @@
+"""Device-side mirror of the reference's tile fusion interface.
+
+Mirrors ``image_stitcher/stitcher.py`` (place_tile / place_single_channel_tile /
+apply_flatfield_correction / compute_mip / the tile loop of stitch_region) and
+``apply_flatfield_to_image`` of ``registration/tile_registration.py`` in the
+reference.  The host-side scalar arithmetic that feeds the kernels (pixel
+offsets, mosaic size, placement order) is reproduced here in float64 exactly
+as the reference evaluates it.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import FF_F32, FF_F64, FF_NONE, FUSE_FEATHER, FUSE_OVERWRITE, check, lib, ptr
+from .registration import to_device_u16
+
+
+def _torch():
+    import torch
+    return torch
+
+
+# ---- host scalars (stitcher.py:392-397, parameters.py:374-382, 1009-1021) ----
+def pixel_size_um(sensor_pixel_size_um: float, magnification: float, tube_lens_f_mm: float,
+                  tube_lens_mm: float) -> float:
+    return sensor_pixel_size_um / (tube_lens_mm / (tube_lens_f_mm / magnification))
+
+
+def pixel_offset(pos_mm: float, min_mm: float, px_um: float) -> int:
+    return int((pos_mm - min_mm) * 1000 / px_um)
+
+
+def output_dimensions(x_mm: Sequence[float], y_mm: Sequence[float], tile_h: int, tile_w: int,
+                      px_um: float) -> Tuple[int, int]:
+    """(width_px, height_px)."""
+    width_mm = max(x_mm) - min(x_mm) + (tile_w * px_um / 1000)
+    height_mm = max(y_mm) - min(y_mm) + (tile_h * px_um / 1000)
+    return int(np.ceil(width_mm * 1000 / px_um)), int(np.ceil(height_mm * 1000 / px_um))
+
+
+def placement_order(filenames: Sequence[str]) -> np.ndarray:
+    """Index permutation that puts tiles in the reference's placement order: sorted
+    file paths (parameters.py:614-621), so in overlaps the lexicographically last
+    file wins."""
+    return np.asarray(sorted(range(len(filenames)), key=lambda i: filenames[i]), dtype=np.int64)
+
+
+def _ff_type(flatfields) -> int:
+    torch = _torch()
+    if flatfields is None:
+        return FF_NONE
+    if flatfields.dtype == torch.float32:
+        return FF_F32
+    if flatfields.dtype == torch.float64:
+        return FF_F64
+    raise TypeError(f"flatfield must be float32 or float64, got {flatfields.dtype}")
+
+
+def _to_device_float(arr, device):
+    torch = _torch()
+    if isinstance(arr, torch.Tensor):
+        return arr.to(device).contiguous()
+    a = np.ascontiguousarray(arr)
+    if a.dtype not in (np.float32, np.float64):
+        raise TypeError(f"flatfield must be float32 or float64, got {a.dtype}")
+    return torch.from_numpy(a).to(device)
+
+
+# ---- kernels -----------------------------------------------------------------
+def apply_flatfield_to_image(image, flatfield, dtype=None):
+    """``(image / flatfield).clip(0, 65535).astype(uint16)`` on the device
+    (tile_registration.py:2142-2181).  NumPy in -> NumPy out; tensors in -> tensor out.
+    ``image`` may be [H, W] or [N, H, W]; the flatfield plane is shared."""
+    torch = _torch()
+    is_np = not isinstance(image, torch.Tensor)
+    img_shape = tuple(image.shape)
+    if tuple(img_shape[-2:]) != tuple(flatfield.shape) or len(img_shape) not in (2, 3):
+        raise ValueError(f"Flatfield shape {tuple(flatfield.shape)} doesn't match image shape {img_shape}")
+    if dtype is not None and np.dtype(dtype) != np.uint16:
+        raise TypeError("only uint16 output is supported")
+    t = to_device_u16(image)
+    ff = _to_device_float(flatfield, t.device)
+    out = torch.empty(t.shape, dtype=torch.int16, device=t.device).view(torch.uint16)
+    n = 1 if t.dim() == 2 else int(t.shape[0])
+    h, w = (int(s) for s in t.shape[-2:])
+    ctx = _lib.default_context()
+    check(lib.mistitch_apply_flatfield(ctx.handle, ptr(t), ptr(ff), _ff_type(ff), ptr(out), n, h, w))
+    return out.cpu().numpy() if is_np else out
+
+
+def compute_mip(tiles):
+    """Per-pixel maximum over a list of equal-shape uint16 tiles (stitcher.py:102-121)."""
+    torch = _torch()
+    if tiles is None or len(tiles) == 0:
+        raise ValueError("Cannot compute MIP from empty tile list")
+    is_np = not isinstance(tiles[0], torch.Tensor)
+    if isinstance(tiles, torch.Tensor):
+        stack = to_device_u16(tiles)
+    elif is_np:
+        stack = to_device_u16(np.stack([np.asarray(t) for t in tiles]))
+    else:  # list of tensors: stack through int16 views (uint16 has few torch kernels)
+        stack = torch.stack([to_device_u16(t).view(torch.int16) for t in tiles]).view(torch.uint16)
+    n = int(stack.shape[0])
+    npx = int(stack[0].numel())
+    out = torch.empty(stack.shape[1:], dtype=torch.int16, device=stack.device).view(torch.uint16)
+    ctx = _lib.default_context()
+    check(lib.mistitch_mip(ctx.handle, ptr(stack), n, npx, npx, ptr(out)))
+    return out.cpu().numpy() if is_np else out
+
+
+def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_w: int,
+               flatfields=None, tile_ff=None, mode: str = "overwrite", rows: Optional[Tuple[int, int]] = None,
+               out=None, ctx: Optional[_lib.Context] = None):
+    """Fuse tiles (given IN PLACEMENT ORDER) into ``[n_planes, mosaic_h, mosaic_w]`` uint16.
+
+    tiles      [T, H, W] uint16 (CUDA tensor, or NumPy array that is uploaded)
+    tile_yx    [T, 2] int32 mosaic positions (y, x)
+    tile_plane [T] int32 destination plane (channel * Z + z)
+    flatfields [F, H, W] float32/float64 or None; tile_ff [T] int32 plane per tile (-1 none)
+    rows       (row0, row1): only this band of every plane is written (multi-GPU sharding)
+    """
+    torch = _torch()
+    tiles = to_device_u16(tiles)
+    if tiles.dim() != 3:
+        raise ValueError(f"tiles must be [T, H, W], got {tuple(tiles.shape)}")
+    dev = tiles.device
+    n_tiles, h, w = (int(s) for s in tiles.shape)
+    yx = torch.as_tensor(np.asarray(tile_yx, dtype=np.int32).reshape(-1, 2) if not isinstance(tile_yx, torch.Tensor)
+                         else tile_yx).to(device=dev, dtype=torch.int32).contiguous()
+    pl = torch.as_tensor(np.asarray(tile_plane, dtype=np.int32).reshape(-1) if not isinstance(tile_plane, torch.Tensor)
+                         else tile_plane).to(device=dev, dtype=torch.int32).contiguous()
+    if int(yx.shape[0]) != n_tiles or int(pl.shape[0]) != n_tiles:
+        raise ValueError("tile_yx / tile_plane do not match the number of tiles")
+    ff = tff = None
+    if flatfields is not None:
+        ff = _to_device_float(flatfields, dev)
+        if ff.dim() == 2:
+            ff = ff.unsqueeze(0)
+        if tuple(ff.shape[-2:]) != (h, w):
+            raise ValueError(f"Flatfield shape {tuple(ff.shape[-2:])} doesn't match image shape {(h, w)}")
+        if tile_ff is None:
+            raise ValueError("tile_ff is required with flatfields")
+        tff = torch.as_tensor(np.asarray(tile_ff, dtype=np.int32).reshape(-1) if not isinstance(tile_ff, torch.Tensor)
+                              else tile_ff).to(device=dev, dtype=torch.int32).contiguous()
+    if out is None:
+        alloc = torch.zeros if rows is not None else torch.empty
+        out = alloc((n_planes, mosaic_h, mosaic_w), dtype=torch.int16, device=dev).view(torch.uint16)
+    row0, row1 = (0, mosaic_h) if rows is None else (int(rows[0]), int(rows[1]))
+    mode_id = {"overwrite": FUSE_OVERWRITE, "feather": FUSE_FEATHER}[mode]
+    ctx = ctx or _lib.default_context()
+    check(lib.mistitch_fuse(ctx.handle, ptr(tiles), n_tiles, h, w, h * w, ptr(yx), ptr(pl), ptr(ff), _ff_type(ff),
+                            ptr(tff), ptr(out), int(n_planes), int(mosaic_h), int(mosaic_w), row0, row1, mode_id))
+    return out
+
+
+# ---- the stitch_region tile loop ---------------------------------------------
+@dataclass
+class TileInfo:
+    """What the reference's AcquisitionMetadata carries for one image file."""
+    filename: str
+    x_mm: float
+    y_mm: float
+    z_level: int
+    channel: str
+
+
+def stitch_region(tiles, infos: Sequence[TileInfo], channel_names: Sequence[str], px_um: float,
+                  flatfields: Optional[Dict[int, np.ndarray]] = None, apply_flatfield: bool = False,
+                  selected_z: Optional[Sequence[int]] = None, mode: str = "overwrite",
+                  update_progress: Optional[Callable[[int, int], None]] = None):
+    """Device replacement of the non-MIP tile loop of ``Stitcher.stitch_region``
+    (stitcher.py:313-410): returns the 5-D ``(1, C, Z, H, W)`` uint16 CUDA tensor.
+
+    tiles[i] belongs to infos[i]; placement happens in sorted-filename order, the
+    channel index is the position in ``channel_names`` and z levels map to their
+    rank among the selected levels, as in the reference.
+    """
+    torch = _torch()
+    tiles = to_device_u16(tiles)
+    h, w = (int(s) for s in tiles.shape[-2:])
+    zs = sorted(set(i.z_level for i in infos)) if selected_z is None else sorted(set(selected_z))
+    z_index = {z: k for k, z in enumerate(zs)}
+    keep = [i for i in range(len(infos)) if infos[i].z_level in z_index]
+    order = [keep[j] for j in placement_order([infos[i].filename for i in keep])]
+    x_min = min(i.x_mm for i in infos)
+    y_min = min(i.y_mm for i in infos)
+    width, height = output_dimensions([i.x_mm for i in infos], [i.y_mm for i in infos], h, w, px_um)
+    n_c, n_z = len(channel_names), len(zs)
+    yx = np.array([[pixel_offset(infos[i].y_mm, y_min, px_um), pixel_offset(infos[i].x_mm, x_min, px_um)]
+                   for i in order], dtype=np.int32).reshape(-1, 2)
+    cidx = [list(channel_names).index(infos[i].channel) for i in order]
+    plane = np.array([c * n_z + z_index[infos[i].z_level] for c, i in zip(cidx, order)], dtype=np.int32)
+    ffs = tff = None
+    if apply_flatfield and flatfields:
+        keys = sorted(flatfields.keys())
+        ffs = np.stack([np.asarray(flatfields[k]) for k in keys])
+        tff = np.array([keys.index(c) if c in flatfields else -1 for c in cidx], dtype=np.int32)
+    idx = torch.as_tensor(np.asarray(order, dtype=np.int64), device=tiles.device)
+    ordered = tiles.view(torch.int16).index_select(0, idx).view(torch.uint16)
+    mosaic = fuse_tiles(ordered, yx, plane, n_c * n_z, height, width, flatfields=ffs, tile_ff=tff, mode=mode)
+    if update_progress is not None:
+        for done in range(len(order)):
+            update_progress(done, len(order))
+    return mosaic.view(1, n_c, n_z, height, width)

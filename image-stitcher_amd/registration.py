@@ -117,7 +117,7 @@ def compute_single_translation(image1_full: np.ndarray, image2_full: np.ndarray,
         if direction not in ("left", "top"):
             return None
         torch = _torch()
-        tiles = torch.stack([to_device_u16(image1_full), to_device_u16(image2_full)])
+        tiles = to_device_u16(np.stack([np.asarray(image1_full), np.asarray(image2_full)]))
         out, status = register_pairs(tiles, [[0, 1]], [0 if direction == "left" else 1], edge_width, fft)
         st = int(status.cpu()[0])
         if st == PAIR_FEATURELESS:

@@ -1,0 +1,146 @@
+"""HIP fusion / flatfield / projection kernels against the oracle (needs an MI355X)."""
+import numpy as np
+import pytest
+
+from image_stitcher_amd import synth
+from oracle import fusion as ofu
+from fusion_cases import reference_fixture_grid, overlapping_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fu():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from image_stitcher_amd import fusion
+    return fusion
+
+
+def _np(t):
+    return t.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", [(3, 3, 64, 64, 1), (2, 4, 96, 200, 2), (4, 3, 128, 520, 3), (1, 1, 33, 17, 1)])
+def test_overwrite_matches_oracle(fu, shape):
+    rows, cols, th, tw, planes = shape
+    tiles, yx, plane, mh, mw = overlapping_scene(7 + rows, rows, cols, th, tw, n_planes=planes)
+    ref = ofu.fuse_overwrite(tiles, yx, plane, planes, mh, mw)
+    got = _np(fu.fuse_tiles(tiles, yx, plane, planes, mh, mw))
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("ffdt", [np.float32, np.float64])
+@pytest.mark.parametrize("mode", ["overwrite", "feather"])
+def test_flatfield_fusion_matches_oracle(fu, ffdt, mode):
+    tiles, yx, plane, mh, mw = overlapping_scene(21, 3, 3, 72, 136, n_planes=2)
+    ffs = np.stack([synth.make_flatfield(72, 136, dtype=ffdt, amplitude=0.5),
+                    synth.make_flatfield(72, 136, dtype=ffdt, amplitude=0.1)])
+    tile_ff = np.where(plane == 0, 0, 1).astype(np.int32)
+    tile_ff[::5] = -1  # some tiles have no flatfield: left untouched like a missing channel
+    oracle = ofu.fuse_overwrite if mode == "overwrite" else ofu.fuse_feather
+    ref = oracle(tiles, yx, plane, 2, mh, mw, flatfields=ffs, tile_ff=tile_ff)
+    got = _np(fu.fuse_tiles(tiles, yx, plane, 2, mh, mw, flatfields=ffs, tile_ff=tile_ff, mode=mode))
+    assert np.array_equal(got, ref)
+
+
+def test_feather_matches_oracle_and_properties(fu):
+    tiles, yx, plane, mh, mw = overlapping_scene(31, 3, 4, 80, 112, n_planes=1, overlap=0.25)
+    ref = ofu.fuse_feather(tiles, yx, plane, 1, mh, mw)
+    got = _np(fu.fuse_tiles(tiles, yx, plane, 1, mh, mw, mode="feather"))
+    diff = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    assert diff.max() <= 1          # stated tolerance: 1 LSB
+    assert diff.max() == 0          # and in fact identical: same float32 operation order
+    over = _np(fu.fuse_tiles(tiles, yx, plane, 1, mh, mw, mode="overwrite"))
+    cover = np.zeros((1, mh, mw), dtype=int)
+    for t in range(len(tiles)):
+        y, x = yx[t]
+        cover[0, y:y + 80, x:x + 112] += 1
+    assert np.array_equal(got[cover == 1], over[cover == 1])
+    assert (got[cover == 0] == 0).all()
+
+
+def test_row_bands_compose(fu):
+    """Chunk-row sharding: fusing disjoint row bands separately equals one full pass."""
+    import torch
+    tiles, yx, plane, mh, mw = overlapping_scene(41, 4, 3, 64, 96, n_planes=2)
+    full = _np(fu.fuse_tiles(tiles, yx, plane, 2, mh, mw))
+    out = torch.zeros((2, mh, mw), dtype=torch.int16, device="cuda").view(torch.uint16)
+    cuts = [0, 37, 38, 150, mh]
+    for r0, r1 in zip(cuts[:-1], cuts[1:]):
+        fu.fuse_tiles(tiles, yx, plane, 2, mh, mw, rows=(r0, r1), out=out)
+    assert np.array_equal(_np(out), full)
+
+
+def test_many_tiles_on_one_block_use_the_slow_path(fu):
+    """More tiles on one output block than the in-LDS list holds."""
+    rng = np.random.default_rng(3)
+    n = 50
+    tiles = rng.integers(0, 65536, size=(n, 24, 40), dtype=np.uint16)
+    yx = rng.integers(0, 12, size=(n, 2)).astype(np.int32)
+    plane = np.zeros(n, dtype=np.int32)
+    for mode, oracle in (("overwrite", ofu.fuse_overwrite), ("feather", ofu.fuse_feather)):
+        ref = oracle(tiles, yx, plane, 1, 40, 56)
+        got = _np(fu.fuse_tiles(tiles, yx, plane, 1, 40, 56, mode=mode))
+        assert np.array_equal(got, ref), mode
+
+
+def test_reference_known_answers(fu):
+    names, x_mm, y_mm, zs, tiles = reference_fixture_grid(3, 3, 1000)
+    infos = [fu.TileInfo(n, x, y, z, "DAPI") for n, x, y, z in zip(names, x_mm, y_mm, zs)]
+    calls = []
+    im = fu.stitch_region(tiles, infos, ["DAPI"], 1.0, update_progress=lambda d, t: calls.append((d, t)))
+    assert tuple(im.shape) == (1, 1, 1, 3000, 3000)
+    im = _np(im)
+    probes = {(0, 0): 0, (1000, 0): 3, (1500, 0): 3, (2000, 0): 6, (0, 1000): 1, (0, 1500): 1,
+              (0, 2000): 2, (2999, 2999): 8}
+    for (y, x), v in probes.items():
+        assert im[0, 0, 0, y, x] == v
+    assert calls == [(i, 9) for i in range(9)]
+
+
+def test_stitch_region_z_and_channels(fu):
+    names, x_mm, y_mm, zs, tiles = reference_fixture_grid(2, 2, 50, num_z=3)
+    infos = [fu.TileInfo(n, x, y, z, "DAPI") for n, x, y, z in zip(names, x_mm, y_mm, zs)]
+    # 50 um fields on a 1 mm pitch would leave gaps; use 20 um pixels so tiles abut
+    px = 20.0
+    im = _np(fu.stitch_region(tiles, infos, ["DAPI"], px, selected_z=[1]))
+    assert im.shape == (1, 1, 1, 100, 100)
+    assert im[0, 0, 0, 0, 0] == 1 and im[0, 0, 0, 0, 50] == 4 and im[0, 0, 0, 50, 0] == 7 and im[0, 0, 0, 99, 99] == 10
+    im = _np(fu.stitch_region(tiles, infos, ["DAPI"], px))
+    assert im.shape == (1, 1, 3, 100, 100)
+    assert im[0, 0, 2, 60, 60] == 11
+
+
+def test_apply_flatfield_vectors_from_reference(fu, golden):
+    f = golden["flatfield"]
+    h, w = f["shape"]
+    ramp = (np.arange(h * w, dtype=np.uint32).reshape(h, w) * 11 % 65536).astype(np.uint16)
+    ramp[0, :8] = [0, 1, 65535, 65534, 40000, 50000, 60000, 32767]
+    for dt, exp in f["results"].items():
+        ff = synth.make_flatfield(h, w, dtype=np.dtype(dt), amplitude=f["amplitude"])
+        got = fu.apply_flatfield_to_image(ramp, ff)
+        assert got.dtype == np.uint16
+        assert np.array_equal(got, ofu.apply_flatfield(ramp, ff))
+        assert int(got.astype(np.int64).sum()) == exp["sum"]
+        assert got[0].tolist() == exp["first_row"] and got[-1].tolist() == exp["last_row"]
+    with pytest.raises(ValueError):
+        fu.apply_flatfield_to_image(ramp, np.ones((h, w + 1), dtype=np.float32))
+    # odd sizes exercise the scalar tail
+    odd = ramp[:13, :11].copy()
+    ffo = synth.make_flatfield(13, 11, amplitude=0.3)
+    stack = np.stack([odd, odd[::-1].copy()])
+    assert np.array_equal(fu.apply_flatfield_to_image(stack, ffo),
+                          np.stack([ofu.apply_flatfield(s, ffo) for s in stack]))
+
+
+def test_mip(fu):
+    tiles = [np.array([[1, 2], [3, 4]], dtype=np.uint16), np.array([[5, 1], [7, 3]], dtype=np.uint16),
+             np.array([[2, 6], [1, 0]], dtype=np.uint16)]
+    assert np.array_equal(fu.compute_mip(tiles), np.array([[5, 6], [7, 4]]))
+    rng = np.random.default_rng(0)
+    stack = rng.integers(0, 65536, size=(5, 37, 53), dtype=np.uint16)
+    assert np.array_equal(fu.compute_mip(list(stack)), ofu.compute_mip(list(stack)))
+    with pytest.raises(ValueError):
+        fu.compute_mip([])
