@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""Benchmark of the registration-and-fusion hot path on MI355X.
+
+One "step" = one pass of the hot path over one synthetic acquisition that is
+already resident in HBM: flatfield-correct the registration channel, register
+every neighbouring tile pair, (N > 1: all-gather the pair rows over RCCL), and
+fuse all channels with flatfield correction into the mosaic.  Registration and
+fusion are timed in separate bracketed regions of K steps each because the
+metric has two units (tile pairs/s and fused MPix/s).
+
+Scaling is weak: every rank owns one whole acquisition (an independent region,
+as wells or timepoints are), so `value` sums over ranks.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|small]
+
+Under torch.distributed.run the RANK / LOCAL_RANK / WORLD_SIZE variables select
+the rank's GPU; rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak
+
+WORKLOADS = {
+    # name: rows, cols, tile, channels, flatfield, label
+    "c3": dict(rows=20, cols=20, tile=2048, channels=4, flatfield=True,
+               label="20x20 grid of 2048^2 uint16 tiles, 4 channels + flatfield, 10% overlap, edge_width 256"),
+    "c2": dict(rows=10, cols=10, tile=2048, channels=1, flatfield=False,
+               label="10x10 grid of 2048^2 uint16 tiles, 1 channel, 10% overlap, edge_width 256"),
+    "small": dict(rows=4, cols=4, tile=512, channels=2, flatfield=True,
+                  label="4x4 grid of 512^2 uint16 tiles, 2 channels + flatfield (debug size)"),
+}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--fft", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--fuse-mode", default="feather", choices=["feather", "overwrite"])
+    ap.add_argument("--edge-width", type=int, default=None)
+    ap.add_argument("--pair-chunk", type=int, default=None)
+    ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    return ap.parse_args()
+
+
+def union_area(yx, h, w):
+    """Pixels covered by at least one h x w tile (coordinate-compressed paint)."""
+    ys = np.unique(np.concatenate([yx[:, 0], yx[:, 0] + h]))
+    xs = np.unique(np.concatenate([yx[:, 1], yx[:, 1] + w]))
+    grid = np.zeros((len(ys) - 1, len(xs) - 1), dtype=bool)
+    for y, x in yx:
+        grid[np.searchsorted(ys, y):np.searchsorted(ys, y + h), np.searchsorted(xs, x):np.searchsorted(xs, x + w)] = True
+    return int((np.diff(ys)[:, None] * np.diff(xs)[None, :] * grid).sum())
+
+
+def build_device_acquisition(cfg, seed, device):
+    """Tiles [C, N, H, W] uint16 cut on the device from white-noise scenes, plus geometry."""
+    import torch
+    from image_stitcher_amd import synth
+
+    rows, cols, t, ch = cfg["rows"], cfg["cols"], cfg["tile"], cfg["channels"]
+    jitter = 3
+    pitch = t - int(round(t * 0.10))
+    sh = (rows - 1) * pitch + t + 2 * jitter
+    sw = (cols - 1) * pitch + t + 2 * jitter
+    rng = np.random.default_rng(seed + 7919)
+    jit = rng.integers(-jitter, jitter + 1, size=(rows * cols, 2))
+    jit[0] = 0
+    true_yx = np.array([[jitter + r * pitch + jit[r * cols + c, 0], jitter + c * pitch + jit[r * cols + c, 1]]
+                        for r in range(rows) for c in range(cols)], dtype=np.int64)
+    tiles = torch.empty((ch, rows * cols, t, t), dtype=torch.int16, device=device)
+    gen = torch.Generator(device=device)
+    for c in range(ch):
+        gen.manual_seed(seed * 1000 + c)
+        scene = torch.rand((sh, sw), generator=gen, device=device)
+        scene = (1000.0 + 30000.0 * scene).to(torch.int16)  # <= 31000: same bits as uint16
+        for n, (y0, x0) in enumerate(true_yx):
+            tiles[c, n] = scene[y0:y0 + t, x0:x0 + t]
+        del scene
+    pair_idx, pair_dir = synth.grid_pairs(rows, cols)
+    return tiles.view(torch.uint16), true_yx, pair_idx, pair_dir
+
+
+def cpu_baseline(n_pairs_target, edge_width, tile, fuse_mode, with_ff):
+    """Time the NumPy oracle (single thread, serial loops, as the reference runs) on a bounded sample."""
+    from image_stitcher_amd import synth
+    from oracle import fusion as ofu
+    from oracle import registration as oreg
+
+    side = 2
+    while 2 * side * side - 2 * side < n_pairs_target:
+        side += 1
+    g = synth.make_grid(99, side, side, tile, tile, overlap=0.10, jitter=3)
+    n = min(n_pairs_target, len(g.pair_idx))
+    ff = synth.make_flatfield(tile, tile)
+    t0 = time.perf_counter()
+    corrected = np.stack([ofu.apply_flatfield(x, ff) for x in g.tiles]) if with_ff else g.tiles
+    out, _ = oreg.register_pairs(corrected, g.pair_idx[:n], g.pair_dir[:n], edge_width, polish=True)
+    t_reg = time.perf_counter() - t0
+    yx = (g.true_yx - g.true_yx.min(axis=0)).astype(np.int32)
+    mh, mw = int(yx[:, 0].max()) + tile, int(yx[:, 1].max()) + tile
+    plane = np.zeros(len(g.tiles), dtype=np.int32)
+    nf = min(len(g.tiles), 9)
+    t0 = time.perf_counter()
+    fuse = ofu.fuse_feather if fuse_mode == "feather" else ofu.fuse_overwrite
+    fuse(g.tiles[:nf], yx[:nf], plane[:nf], 1, mh, mw, flatfields=ff[None] if with_ff else None,
+         tile_ff=plane[:nf] if with_ff else None)
+    t_fuse = time.perf_counter() - t0
+    mpix = union_area(yx[:nf], tile, tile) / 1e6
+    return dict(pairs=n, t_reg=t_reg, t_fuse=t_fuse, fused_mpix=mpix, tiles_fused=nf, grid_side=side)
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from image_stitcher_amd import _lib, synth
+    from image_stitcher_amd import dist as mdist
+    from image_stitcher_amd._lib import check, lib, ptr
+
+    cfg = WORKLOADS[args.workload]
+    tile, ch = cfg["tile"], cfg["channels"]
+    edge = args.edge_width or (256 if tile >= 2048 else tile // 8)
+    fft_flag = _lib.FFT_F64 if args.fft == "f64" else _lib.FFT_F32
+    mode_id = _lib.FUSE_FEATHER if args.fuse_mode == "feather" else _lib.FUSE_OVERWRITE
+
+    ctx = _lib.Context(local_rank, torch.cuda.current_stream(device).cuda_stream, pair_chunk=args.pair_chunk)
+    tiles, true_yx, pair_idx, pair_dir = build_device_acquisition(cfg, seed=3 + rank, device=device)
+    n_tiles = cfg["rows"] * cfg["cols"]
+    n_pairs = len(pair_idx)
+    yx_np = (true_yx - true_yx.min(axis=0)).astype(np.int32)
+    mosaic_h, mosaic_w = int(yx_np[:, 0].max()) + tile, int(yx_np[:, 1].max()) + tile
+
+    # device-resident descriptors and outputs (nothing below allocates inside the timed loops
+    # once the library workspaces have been sized by the warm-up steps)
+    d_pair_idx = torch.as_tensor(pair_idx, dtype=torch.int32, device=device)
+    d_pair_dir = torch.as_tensor(pair_dir, dtype=torch.uint8, device=device)
+    d_out = torch.empty((n_pairs, 3), dtype=torch.float64, device=device)
+    d_status = torch.empty((n_pairs,), dtype=torch.int8, device=device)
+    d_yx = torch.as_tensor(np.tile(yx_np, (ch, 1)), dtype=torch.int32, device=device)
+    d_plane = torch.as_tensor(np.repeat(np.arange(ch), n_tiles), dtype=torch.int32, device=device)
+    mosaic = torch.empty((ch, mosaic_h, mosaic_w), dtype=torch.int16, device=device).view(torch.uint16)
+    ffs = None
+    reg_tiles = tiles[0]
+    if cfg["flatfield"]:
+        ffs = torch.as_tensor(np.stack([synth.make_flatfield(tile, tile, amplitude=0.2 - 0.03 * c) for c in range(ch)]),
+                              device=device)
+        reg_tiles = torch.empty((n_tiles, tile, tile), dtype=torch.int16, device=device).view(torch.uint16)
+    ff_type = _lib.FF_F32 if ffs is not None else _lib.FF_NONE
+    counts = [n_pairs] * world
+    gathered = None
+
+    def step_registration():
+        nonlocal gathered
+        if ffs is not None:
+            check(lib.mistitch_apply_flatfield(ctx.handle, ptr(tiles[0]), ptr(ffs[0]), ff_type, ptr(reg_tiles),
+                                               n_tiles, tile, tile))
+        check(lib.mistitch_register_pairs(ctx.handle, ptr(reg_tiles), n_tiles, tile, tile, tile * tile,
+                                          ptr(d_pair_idx), ptr(d_pair_dir), n_pairs, edge, fft_flag,
+                                          ptr(d_out), ptr(d_status)))
+        if world > 1:
+            gathered = mdist.all_gather_pair_results(d_out, d_status, counts)
+
+    def step_fusion():
+        check(lib.mistitch_fuse(ctx.handle, ptr(tiles), ch * n_tiles, tile, tile, tile * tile, ptr(d_yx), ptr(d_plane),
+                                ptr(ffs), ff_type, ptr(d_plane) if ffs is not None else ptr(None), ptr(mosaic), ch,
+                                mosaic_h, mosaic_w, 0, mosaic_h, mode_id))
+
+    def bracket():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, k):
+        bracket()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        bracket()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range(args.warmup):
+        step_registration()
+        step_fusion()
+    t_reg = timed(step_registration, args.steps)
+    t_fuse = timed(step_fusion, args.steps)
+
+    # ---- parity properties at full size: every planted shift recovered, mosaic spot checks ----
+    out_np, st_np = d_out.cpu().numpy(), d_status.cpu().numpy()
+    expected = true_yx[pair_idx[:, 1]] - true_yx[pair_idx[:, 0]]
+    shifts_ok = bool((st_np == 0).all() and np.array_equal(out_np[:, 1:].astype(np.int64), expected))
+
+    # ---- per-kernel durations from HIP events on the launch stream ----
+    kernels = {}
+    if not args.no_profile:
+        ctx.profile(True)
+        psteps = 2
+        for _ in range(psteps):
+            step_registration()
+            step_fusion()
+        for name, (ms, launches) in ctx.profile_collect().items():
+            kernels[name] = dict(ms_per_step=ms / psteps, launches_per_step=launches / psteps,
+                                 avg_launch_us=1e3 * ms / launches)
+        ctx.profile(False)
+
+    # ---- algorithmic bytes ----
+    strip_px = edge * tile
+    reg_bytes_per_pair = 2 * strip_px * 2                      # two uint16 strips in
+    cplx = 16 if args.fft == "f64" else 8
+    covered = union_area(yx_np, tile, tile)
+    clipped_tile_px = n_tiles * tile * tile                    # every tile lies inside the mosaic here
+    fuse_bytes = ch * ((2 * clipped_tile_px + 2 * mosaic_h * mosaic_w) if args.fuse_mode == "feather"
+                       else (4 * covered + 2 * (mosaic_h * mosaic_w - covered)))
+    if ffs is not None:
+        fuse_bytes += ch * tile * tile * 4                     # flatfield planes, read once (cache resident)
+    alg_bytes_per_step = {
+        "k_fft_long_fwd": n_pairs * (2 * strip_px * 2 + strip_px * cplx),
+        "k_fft_short_cps": n_pairs * (strip_px * cplx + (strip_px // 2) * cplx),
+        "k_fft_long_inv": n_pairs * (strip_px // 2) * cplx,
+        "k_ncc_accumulate": n_pairs * 2 * strip_px * 2,
+        "k_transpose_strips": int((pair_dir == 0).sum()) * 2 * strip_px * 2 * 2,
+        "k_flatfield": n_tiles * tile * tile * 4 + tile * tile * 4,
+        "k_fuse_feather": fuse_bytes, "k_fuse_overwrite": fuse_bytes,
+    }
+    rooflines = {}
+    for name, k in kernels.items():
+        if name in alg_bytes_per_step and k["ms_per_step"] > 0:
+            gbs = alg_bytes_per_step[name] / (k["ms_per_step"] * 1e-3) / 1e9
+            rooflines[name] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                                   frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                                   avg_launch_us=round(k["avg_launch_us"], 2),
+                                   algorithmic_bytes_per_launch=int(alg_bytes_per_step[name] / k["launches_per_step"]))
+    dominant = max(rooflines, key=lambda n: kernels[n]["ms_per_step"]) if rooflines else None
+
+    pairs_per_s = world * n_pairs * args.steps / t_reg
+    mpix_per_step = ch * mosaic_h * mosaic_w / 1e6
+    mpix_per_s = world * mpix_per_step * args.steps / t_fuse
+    fuse_gbs = fuse_bytes * args.steps / t_fuse / 1e9            # per GPU
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_pairs > 0:
+        cpu = cpu_baseline(args.cpu_pairs, edge, tile, args.fuse_mode, cfg["flatfield"])
+
+    if rank == 0:
+        line = {
+            "metric": "tile_pairs_registered_per_sec",
+            "value": round(pairs_per_s, 1),
+            "unit": "tile-pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * (t_reg + t_fuse) / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64" if args.fft == "f64" else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {cfg['label']}, one acquisition per GPU",
+                       "pairs_per_gpu": n_pairs, "edge_width": edge, "fft": args.fft,
+                       "fuse_mode": args.fuse_mode, "mosaic": [ch, mosaic_h, mosaic_w]},
+            "registration": {"ms_per_step": round(1e3 * t_reg / args.steps, 3),
+                             "includes": ("flatfield of the registration channel, " if ffs is not None else "")
+                             + "register_pairs" + (", RCCL all-gather of pair rows" if world > 1 else ""),
+                             "roofline_whole_path": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                                     "achieved": round(pairs_per_s / world * reg_bytes_per_pair / 1e9, 1),
+                                                     "frac": round(pairs_per_s / world * reg_bytes_per_pair / 1e9
+                                                                   / HBM_PEAK_GBS, 4),
+                                                     "algorithmic_bytes_per_pair": reg_bytes_per_pair}},
+            "fusion": {"metric": "fused_mosaic_MPix_per_sec", "value": round(mpix_per_s, 1), "unit": "MPix/s",
+                       "dtype": "u16", "mode": args.fuse_mode, "ms_per_step": round(1e3 * t_fuse / args.steps, 3),
+                       "roofline": {"bound": "hbm", "achieved": round(fuse_gbs, 1), "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": round(fuse_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                    "algorithmic_bytes_per_launch": int(fuse_bytes)}},
+            "parity": {"planted_integer_shifts_recovered": shifts_ok, "pairs_checked": int(n_pairs)},
+            "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
+            "kernels": {n: {**{k: round(v, 3) for k, v in kernels[n].items()},
+                            **({"hbm_frac": rooflines[n]["frac"]} if n in rooflines else {})} for n in kernels},
+        }
+        if cpu is not None:
+            cpu_pairs_s = cpu["pairs"] / cpu["t_reg"]
+            line["cpu_baseline"] = {
+                "value": round(cpu_pairs_s, 3), "unit": "tile-pairs/s", "cores": 1, "kind": "port",
+                "sample": f"{cpu['pairs']} pairs of a {cpu['grid_side']}x{cpu['grid_side']} grid of {tile}^2 tiles "
+                          f"(flatfield + register, NumPy oracle incl. least-squares polish, serial as the reference); "
+                          f"fusion: {cpu['tiles_fused']} tiles, {args.fuse_mode}",
+                "host_cpus": os.cpu_count(),
+                "fusion_value": round(cpu["fused_mpix"] / cpu["t_fuse"], 2), "fusion_unit": "MPix/s",
+                "gpu_over_cpu_registration": round(pairs_per_s / cpu_pairs_s, 1),
+                "gpu_over_cpu_fusion": round(mpix_per_s / (cpu["fused_mpix"] / cpu["t_fuse"]), 1),
+            }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

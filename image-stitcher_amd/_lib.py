@@ -9,6 +9,11 @@ import ctypes as C
 import os
 from typing import Optional
 
+# torch ships its own HIP runtime; it must be the one already mapped when
+# libmistitch.so is loaded, or the process ends up with two runtimes and the
+# second one finds no device.
+import torch  # noqa: F401  (import order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmistitch.so")
 
@@ -24,6 +29,7 @@ EXPORTS = [
     "mistitch_set_pair_chunk", "mistitch_reserve_registration", "mistitch_register_pairs",
     "mistitch_pcm", "mistitch_pcm_topk", "mistitch_ncc", "mistitch_edge_variance",
     "mistitch_apply_flatfield", "mistitch_fuse", "mistitch_mip", "mistitch_synchronize",
+    "mistitch_profile_enable", "mistitch_profile_collect",
 ]
 
 
@@ -56,6 +62,9 @@ def _load() -> C.CDLL:
         "mistitch_fuse": [vp, vp, i32, i32, i32, i64, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32],
         "mistitch_mip": [vp, vp, i32, i64, i64, vp],
         "mistitch_synchronize": [vp],
+        "mistitch_profile_enable": [vp, i32],
+        "mistitch_profile_collect": [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(i32), i32,
+                                     C.POINTER(i32)],
     }
     for name, argtypes in sigs.items():
         fn = getattr(lib, name)
@@ -103,6 +112,21 @@ class Context:
 
     def synchronize(self) -> None:
         check(lib.mistitch_synchronize(self.handle))
+
+    def profile(self, on: bool) -> None:
+        """Start (or stop) recording HIP events around every kernel this context launches."""
+        check(lib.mistitch_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_collect(self):
+        """{kernel name: (total milliseconds, launches)} since profiling was enabled / last collected."""
+        cap = 64
+        names = C.create_string_buffer(4096)
+        ms = (C.c_double * cap)()
+        cnt = (C.c_int * cap)()
+        n = C.c_int(0)
+        check(lib.mistitch_profile_collect(self.handle, names, 4096, ms, cnt, cap, C.byref(n)))
+        keys = names.value.decode().split("\n") if n.value else []
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(keys)}
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None:

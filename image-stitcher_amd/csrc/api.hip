@@ -30,6 +30,7 @@ extern "C" int mistitch_destroy(mistitch_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->desc, &ctx->staging, &ctx->spectrum, &ctx->partial, &ctx->peaks,
                     &ctx->cand, &ctx->acc,     &ctx->misc,     &ctx->bins};
   for (DevBuf* b : bufs) b->release();
+  ctx->prof.destroy();
   delete ctx;
   return MISTITCH_OK;
 }
@@ -45,5 +46,49 @@ extern "C" int mistitch_synchronize(mistitch_ctx* ctx) {
   MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
   MS_HIP(hipSetDevice(ctx->device));
   MS_HIP(hipStreamSynchronize(ctx->stream));
+  return MISTITCH_OK;
+}
+
+extern "C" int mistitch_profile_enable(mistitch_ctx* ctx, int on) {
+  MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
+  MS_HIP(hipSetDevice(ctx->device));
+  MS_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->prof.release();
+  ctx->prof.on = on != 0;
+  return MISTITCH_OK;
+}
+
+extern "C" int mistitch_profile_collect(mistitch_ctx* ctx, char* names, size_t names_len, double* total_ms,
+                                        int* launches, int max_entries, int* n_entries) {
+  MS_REQUIRE(ctx && names && total_ms && launches && n_entries, MISTITCH_ERR_ARG, "NULL argument");
+  MS_HIP(hipSetDevice(ctx->device));
+  MS_HIP(hipStreamSynchronize(ctx->stream));
+  std::vector<std::string> order;
+  std::map<std::string, std::pair<double, int>> agg;
+  for (auto& r : ctx->prof.recs) {
+    float ms = 0.f;
+    MS_HIP(hipEventElapsedTime(&ms, r.e0, r.e1));
+    auto it = agg.find(r.name);
+    if (it == agg.end()) {
+      order.push_back(r.name);
+      agg[r.name] = {ms, 1};
+    } else {
+      it->second.first += ms;
+      it->second.second += 1;
+    }
+  }
+  ctx->prof.release();
+  MS_REQUIRE((int)order.size() <= max_entries, MISTITCH_ERR_ARG, "%zu kernels do not fit %d entries", order.size(),
+             max_entries);
+  std::string joined;
+  for (size_t i = 0; i < order.size(); ++i) {
+    if (i) joined += "\n";
+    joined += order[i];
+    total_ms[i] = agg[order[i]].first;
+    launches[i] = agg[order[i]].second;
+  }
+  MS_REQUIRE(joined.size() + 1 <= names_len, MISTITCH_ERR_ARG, "names buffer too small");
+  memcpy(names, joined.c_str(), joined.size() + 1);
+  *n_entries = (int)order.size();
   return MISTITCH_OK;
 }

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <set>
+#include <string>
 #include <vector>
 
 #include "../../include/mistitch.h"
@@ -84,7 +86,58 @@ struct FftPlanHost {
   void* blob = nullptr;  // single device allocation backing the tables
 };
 
+// ---- optional per-kernel timing (HIP events on the context's stream) ---------
+struct Profiler {
+  bool on = false;
+  struct Rec {
+    const char* name;
+    hipEvent_t e0, e1;
+  };
+  std::vector<Rec> recs;
+  std::vector<hipEvent_t> pool;
+  hipEvent_t get() {
+    if (!pool.empty()) {
+      hipEvent_t e = pool.back();
+      pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void begin(const char* name, hipStream_t st) {
+    if (!on) return;
+    Rec r{name, get(), get()};
+    (void)hipEventRecord(r.e0, st);
+    recs.push_back(r);
+  }
+  void end(hipStream_t st) {
+    if (!on) return;
+    (void)hipEventRecord(recs.back().e1, st);
+  }
+  void release() {
+    for (auto& r : recs) {
+      pool.push_back(r.e0);
+      pool.push_back(r.e1);
+    }
+    recs.clear();
+  }
+  void destroy() {
+    release();
+    for (hipEvent_t e : pool) (void)hipEventDestroy(e);
+    pool.clear();
+  }
+};
+
 }  // namespace mistitch
+
+// Launch on the context's stream, timed when profiling is enabled.
+#define MS_LAUNCH(ctx, name, kernel, grid, block, lds, ...)                     \
+  do {                                                                          \
+    (ctx)->prof.begin(name, (ctx)->stream);                                     \
+    hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__);   \
+    (ctx)->prof.end((ctx)->stream);                                             \
+  } while (0)
 
 // The opaque handle of the C ABI.
 struct mistitch_ctx {
@@ -94,4 +147,6 @@ struct mistitch_ctx {
   std::map<long long, mistitch::FftPlanHost> plans;  // key = n * 2 + (is_f64)
   mistitch::DevBuf desc, staging, spectrum, partial, peaks, cand, acc, misc, bins;
   std::vector<char> host_scratch;
+  std::set<const void*> lds_enabled;  // kernels already granted large dynamic LDS
+  mistitch::Profiler prof;
 };

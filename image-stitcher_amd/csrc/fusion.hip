@@ -289,10 +289,11 @@ __global__ __launch_bounds__(256) void k_mip(const uint16_t* __restrict__ in, in
 }
 
 template <int MODE, int FF>
-static void launch_fuse(hipStream_t st, dim3 grid, const uint16_t* tiles, int n_tiles, int H, int W, int64_t pitch,
+static void launch_fuse(mistitch_ctx* ctx, dim3 grid, const uint16_t* tiles, int n_tiles, int H, int W, int64_t pitch,
                         const int32_t* yx, const int32_t* plane, const void* ffs, const int32_t* tff, uint16_t* mosaic,
                         int Hm, int Wm, int row0, int row1) {
-  hipLaunchKernelGGL((k_fuse<MODE, FF>), grid, dim3(kFuseThreads), 0, st, tiles, n_tiles, H, W, pitch, yx, plane, ffs,
+  MS_LAUNCH(ctx, MODE == MISTITCH_FUSE_OVERWRITE ? "k_fuse_overwrite" : "k_fuse_feather", (k_fuse<MODE, FF>), grid,
+            dim3(kFuseThreads), 0, tiles, n_tiles, H, W, pitch, yx, plane, ffs,
                      tff, mosaic, Hm, Wm, row0, row1);
 }
 
@@ -321,9 +322,8 @@ extern "C" int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_til
   MS_HIP(hipSetDevice(ctx->device));
   const dim3 grid((mosaic_w + kBW - 1) / kBW, (row1 - row0 + kBH - 1) / kBH, n_planes);
   MS_REQUIRE(grid.y <= 65535, MISTITCH_ERR_UNSUPPORTED, "row band too tall for one launch");
-  hipStream_t st = ctx->stream;
 #define MS_FUSE(M, F)                                                                                          \
-  launch_fuse<M, F>(st, grid, tiles, n_tiles, tile_h, tile_w, tile_pitch, tile_yx, tile_plane, flatfields, tile_ff, \
+  launch_fuse<M, F>(ctx, grid, tiles, n_tiles, tile_h, tile_w, tile_pitch, tile_yx, tile_plane, flatfields, tile_ff, \
                     mosaic, mosaic_h, mosaic_w, row0, row1)
   if (mode == MISTITCH_FUSE_OVERWRITE) {
     if (ff_type == MISTITCH_FF_NONE) MS_FUSE(MISTITCH_FUSE_OVERWRITE, MISTITCH_FF_NONE);
@@ -351,13 +351,12 @@ extern "C" int mistitch_apply_flatfield(mistitch_ctx* ctx, const uint16_t* in, c
   const int64_t groups = (npx / 8) * n_tiles;
   const int blocks = (int)std::min<int64_t>((groups + 255) / 256, 256 * 16);
   const int ntail = (int)(npx % 8) * n_tiles;
-  hipStream_t st = ctx->stream;
   if (ff_type == MISTITCH_FF_F32) {
-    if (groups) hipLaunchKernelGGL(k_flatfield<MISTITCH_FF_F32>, dim3(blocks), dim3(256), 0, st, in, flatfield, out, npx, groups);
-    if (ntail) hipLaunchKernelGGL(k_flatfield_tail<MISTITCH_FF_F32>, dim3((ntail + 63) / 64), dim3(64), 0, st, in, flatfield, out, npx, n_tiles);
+    if (groups) MS_LAUNCH(ctx, "k_flatfield", k_flatfield<MISTITCH_FF_F32>, dim3(blocks), dim3(256), 0, in, flatfield, out, npx, groups);
+    if (ntail) MS_LAUNCH(ctx, "k_flatfield_tail", k_flatfield_tail<MISTITCH_FF_F32>, dim3((ntail + 63) / 64), dim3(64), 0, in, flatfield, out, npx, n_tiles);
   } else {
-    if (groups) hipLaunchKernelGGL(k_flatfield<MISTITCH_FF_F64>, dim3(blocks), dim3(256), 0, st, in, flatfield, out, npx, groups);
-    if (ntail) hipLaunchKernelGGL(k_flatfield_tail<MISTITCH_FF_F64>, dim3((ntail + 63) / 64), dim3(64), 0, st, in, flatfield, out, npx, n_tiles);
+    if (groups) MS_LAUNCH(ctx, "k_flatfield", k_flatfield<MISTITCH_FF_F64>, dim3(blocks), dim3(256), 0, in, flatfield, out, npx, groups);
+    if (ntail) MS_LAUNCH(ctx, "k_flatfield_tail", k_flatfield_tail<MISTITCH_FF_F64>, dim3((ntail + 63) / 64), dim3(64), 0, in, flatfield, out, npx, n_tiles);
   }
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
@@ -371,7 +370,7 @@ extern "C" int mistitch_mip(mistitch_ctx* ctx, const uint16_t* in, int n, int64_
   if (n_pixels == 0) return MISTITCH_OK;
   MS_HIP(hipSetDevice(ctx->device));
   const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_pixels / 8 + 255) / 256, 256 * 16));
-  hipLaunchKernelGGL(k_mip, dim3(blocks), dim3(256), 0, ctx->stream, in, n, pitch, n_pixels, out);
+  MS_LAUNCH(ctx, "k_mip", k_mip, dim3(blocks), dim3(256), 0, in, n, pitch, n_pixels, out);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }

@@ -822,10 +822,12 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
 }
 
 template <typename KernelT>
-static int allow_lds(KernelT kernel, size_t bytes) {
-  if (bytes > 48 * 1024)
-    MS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)bytes));
+static int allow_lds(mistitch_ctx* ctx, KernelT kernel, size_t bytes) {
+  const void* fn = reinterpret_cast<const void*>(kernel);
+  if (bytes > 48 * 1024 && !ctx->lds_enabled.count(fn)) {
+    MS_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsMax));
+    ctx->lds_enabled.insert(fn);
+  }
   return MISTITCH_OK;
 }
 
@@ -865,24 +867,23 @@ static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, size_
 template <typename T>
 static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace& ws, const int8_t* status,
                       int pair0, int n, int want_transposed, bool vec_ok, int k, double* pcm_out) {
-  hipStream_t st = ctx->stream;
   cx<T>* spec = reinterpret_cast<cx<T>*>(ws.spectrum);
   int rc;
   if (vec_ok) {
-    if ((rc = allow_lds(k_fft_long_fwd<T, true>, cfg.lds_fwd))) return rc;
-    hipLaunchKernelGGL((k_fft_long_fwd<T, true>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd, st,
+    if ((rc = allow_lds(ctx, k_fft_long_fwd<T, true>, cfg.lds_fwd))) return rc;
+    MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd<T, true>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd,
                        ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, spec);
   } else {
-    if ((rc = allow_lds(k_fft_long_fwd<T, false>, cfg.lds_fwd))) return rc;
-    hipLaunchKernelGGL((k_fft_long_fwd<T, false>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd, st,
+    if ((rc = allow_lds(ctx, k_fft_long_fwd<T, false>, cfg.lds_fwd))) return rc;
+    MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd<T, false>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd,
                        ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, spec);
   }
-  if ((rc = allow_lds(k_fft_short_cps<T>, cfg.lds_cps))) return rc;
+  if ((rc = allow_lds(ctx, k_fft_short_cps<T>, cfg.lds_cps))) return rc;
   const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
-  hipLaunchKernelGGL((k_fft_short_cps<T>), dim3(cfg.L / cfg.C, n), dim3(kThreads), cfg.lds_cps, st, ws.desc, status,
+  MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<T>), dim3(cfg.L / cfg.C, n), dim3(kThreads), cfg.lds_cps, ws.desc, status,
                      pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.C, spec, eps);
-  if ((rc = allow_lds(k_fft_long_inv<T>, cfg.lds_inv))) return rc;
-  hipLaunchKernelGGL((k_fft_long_inv<T>), dim3(cfg.S / (2 * cfg.NF_inv), n), dim3(kThreads), cfg.lds_inv, st, ws.desc,
+  if ((rc = allow_lds(ctx, k_fft_long_inv<T>, cfg.lds_inv))) return rc;
+  MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv<T>), dim3(cfg.S / (2 * cfg.NF_inv), n), dim3(kThreads), cfg.lds_inv, ws.desc,
                      status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.C, cfg.NF_inv, spec, k, ws.partial,
                      ws.partial_stride, pcm_out);
   MS_HIP(hipGetLastError());
@@ -941,18 +942,17 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
   const int chunk = n_pairs < ctx->pair_chunk ? n_pairs : ctx->pair_chunk;
   RegWorkspace ws;
   if ((rc = reserve_registration(ctx, n_pairs, chunk, (size_t)w_left * H * 2, spec, pstride, &ws))) return rc;
-  hipStream_t st = ctx->stream;
   // 16-byte loads of tile rows need aligned rows; staging lines always are.
   const bool vec_top = aligned16(tiles) && (W % 8 == 0) && (tile_pitch % 8 == 0);
   const int k = 2;  // peaks the candidate search consumes
 
-  hipLaunchKernelGGL(k_setup_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, st, tiles, tile_pitch, H, W, w_left,
+  MS_LAUNCH(ctx, "k_setup_pairs", k_setup_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, tiles, tile_pitch, H, W, w_left,
                      w_top, pair_idx, pair_dir, n_pairs, n_tiles, ws.staging, chunk, ws.desc, status);
-  hipLaunchKernelGGL(k_edge_stats, dim3(2, n_pairs), dim3(kThreads), 0, st, tiles, tile_pitch, H, W, w_left, w_top,
+  MS_LAUNCH(ctx, "k_edge_stats", k_edge_stats, dim3(2, n_pairs), dim3(kThreads), 0, tiles, tile_pitch, H, W, w_left, w_top,
                      pair_idx, pair_dir, status, 2e3);
   for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {
     const int n = std::min(chunk, n_pairs - pair0);
-    hipLaunchKernelGGL(k_transpose_strips, dim3((H + 31) / 32, (w_left + 31) / 32, 2 * n), dim3(32, 8), 0, st, tiles,
+    MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips, dim3((H + 31) / 32, (w_left + 31) / 32, 2 * n), dim3(32, 8), 0, tiles,
                        tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
     if (same_shape) {
       // left strips come from the aligned staging buffer, top strips from the tiles
@@ -967,13 +967,13 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
                : launch_fft<float>(ctx, cfg_top, ws, status, pair0, n, 0, vec_top, k, nullptr);
       if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_peaks_candidates, dim3(n), dim3(kThreads), 0, st, ws.desc, status, pair0, ws.partial,
+    MS_LAUNCH(ctx, "k_peaks_candidates", k_peaks_candidates, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, ws.partial,
                        ws.partial_stride, cfg_top.S / (2 * cfg_top.NF_inv), cfg_left.S / (2 * cfg_left.NF_inv), k, 2,
                        ws.peaks, ws.cand, ws.acc);
-    hipLaunchKernelGGL(k_ncc_accumulate, dim3(kNccChunks, kNumCand, n), dim3(kThreads), 0, st, ws.desc, status, pair0,
+    MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(kNccChunks, kNumCand, n), dim3(kThreads), 0, ws.desc, status, pair0,
                        ws.cand, ws.acc);
   }
-  hipLaunchKernelGGL(k_finalize, dim3((n_pairs + 63) / 64), dim3(64), 0, st, ws.desc, status, n_pairs, ws.cand, ws.acc,
+  MS_LAUNCH(ctx, "k_finalize", k_finalize, dim3((n_pairs + 63) / 64), dim3(64), 0, ws.desc, status, n_pairs, ws.cand, ws.acc,
                      out, status);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
@@ -1003,9 +1003,9 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   PairDesc d;
   bool vec = true;
   if (transposed) {
-    hipLaunchKernelGGL(k_transpose_plain, dim3((h + 31) / 32, (w + 31) / 32), dim3(32, 8), 0, st, strip1, pitch1, h, w,
+    MS_LAUNCH(ctx, "k_transpose_plain", k_transpose_plain, dim3((h + 31) / 32, (w + 31) / 32), dim3(32, 8), 0, strip1, pitch1, h, w,
                        ws.staging);
-    hipLaunchKernelGGL(k_transpose_plain, dim3((h + 31) / 32, (w + 31) / 32), dim3(32, 8), 0, st, strip2, pitch2, h, w,
+    MS_LAUNCH(ctx, "k_transpose_plain", k_transpose_plain, dim3((h + 31) / 32, (w + 31) / 32), dim3(32, 8), 0, strip2, pitch2, h, w,
                        ws.staging + (size_t)S * L);
     d.a = ws.staging;
     d.b = ws.staging + (size_t)S * L;
@@ -1040,10 +1040,10 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
            : launch_fft<float>(ctx, cfg, ws, status, 0, 1, -1, vec, k, out_pcm);
   if (rc) return rc;
   if (k > 0) {
-    hipLaunchKernelGGL(k_peaks_candidates, dim3(1), dim3(kThreads), 0, st, ws.desc, status, 0, ws.partial,
+    MS_LAUNCH(ctx, "k_peaks_candidates", k_peaks_candidates, dim3(1), dim3(kThreads), 0, ws.desc, status, 0, ws.partial,
                        ws.partial_stride, cfg.S / (2 * cfg.NF_inv), cfg.S / (2 * cfg.NF_inv), k, 0, ws.peaks,
                        (Cand*)nullptr, (unsigned long long*)nullptr);
-    hipLaunchKernelGGL(k_peaks_to_arrays, dim3(1), dim3(64), 0, st, ws.peaks, k, w, rows, cols, vals);
+    MS_LAUNCH(ctx, "k_peaks_to_arrays", k_peaks_to_arrays, dim3(1), dim3(64), 0, ws.peaks, k, w, rows, cols, vals);
   }
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
@@ -1076,9 +1076,9 @@ extern "C" int mistitch_ncc(mistitch_ctx* ctx, const uint16_t* patch1, int64_t p
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ctx->misc.ptr) + 64);
   MS_HIP(hipMemsetAsync(acc, 0, 5 * sizeof(unsigned long long), st));
   if ((long long)h * w > 0)
-    hipLaunchKernelGGL(k_ncc_single, dim3(h < 1024 ? h : 1024), dim3(kThreads), 0, st, patch1, pitch1, patch2, pitch2,
+    MS_LAUNCH(ctx, "k_ncc_single", k_ncc_single, dim3(h < 1024 ? h : 1024), dim3(kThreads), 0, patch1, pitch1, patch2, pitch2,
                        h, w, acc);
-  hipLaunchKernelGGL(k_ncc_single_finish, dim3(1), dim3(64), 0, st, acc, (long long)h * w, out);
+  MS_LAUNCH(ctx, "k_ncc_single_finish", k_ncc_single_finish, dim3(1), dim3(64), 0, acc, (long long)h * w, out);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }
@@ -1088,7 +1088,7 @@ extern "C" int mistitch_edge_variance(mistitch_ctx* ctx, const uint16_t* strip, 
   MS_REQUIRE(ctx && strip && out_var, MISTITCH_ERR_ARG, "NULL argument");
   MS_REQUIRE(h > 0 && w > 0 && pitch >= w, MISTITCH_ERR_ARG, "bad strip geometry");
   MS_HIP(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(k_variance_single, dim3(1), dim3(kThreads), 0, ctx->stream, strip, pitch, h, w, out_var);
+  MS_LAUNCH(ctx, "k_variance_single", k_variance_single, dim3(1), dim3(kThreads), 0, strip, pitch, h, w, out_var);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }

@@ -154,6 +154,15 @@ int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int til
 int mistitch_mip(mistitch_ctx* ctx, const uint16_t* in, int n, int64_t pitch, int64_t n_pixels,
                  uint16_t* out);
 
+/* Per-kernel timing with HIP events recorded on the context's stream around
+ * every launch (measurement aid; no counterpart in the reference).  Enable,
+ * run any entry points, then collect: kernel names come back '\n'-separated in
+ * first-launch order with the summed milliseconds and launch counts.  Both
+ * calls synchronise the stream.                                                   */
+int mistitch_profile_enable(mistitch_ctx* ctx, int on);
+int mistitch_profile_collect(mistitch_ctx* ctx, char* names, size_t names_len, double* total_ms,
+                             int* launches, int max_entries, int* n_entries);
+
 /* Block the calling thread until the context's stream has drained. */
 int mistitch_synchronize(mistitch_ctx* ctx);
 

@@ -1,0 +1,87 @@
+"""The N>1 partitioning and the pair-result all-gather, on CPU with gloo (world_size 2).
+
+The per-rank compute is stood in for by the oracle: what is under test is the
+sharding, the halo bookkeeping and the collective, not the kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from image_stitcher_amd import dist as mdist
+from image_stitcher_amd import synth
+from oracle import fusion as ofu
+from oracle import registration as oreg
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = synth.make_grid(5, 3, 3, 128, 128, overlap=0.15, jitter=2)
+        mine, tiles_needed = mdist.shard_pairs_by_grid_rows(g.pair_idx, g.cols, g.rows, world, rank)
+        # a rank only touches the tiles of its band plus the halo row above it
+        local_tiles = {int(t): g.tiles[t] for t in tiles_needed}
+        remap = {t: i for i, t in enumerate(sorted(local_tiles))}
+        stack = np.stack([local_tiles[t] for t in sorted(local_tiles)])
+        lp = np.array([[remap[int(a)], remap[int(b)]] for a, b in g.pair_idx[mine]]).reshape(-1, 2)
+        out, st = oreg.register_pairs(stack, lp, g.pair_dir[mine], 32, polish=False)
+        counts = [len(mdist.shard_pairs_by_grid_rows(g.pair_idx, g.cols, g.rows, world, r)[0]) for r in range(world)]
+        rows, status = mdist.all_gather_pair_results(torch.from_numpy(out), torch.from_numpy(st), counts)
+        lists = [mdist.shard_pairs_by_grid_rows(g.pair_idx, g.cols, g.rows, world, r)[0] for r in range(world)]
+        g_rows, g_st = mdist.scatter_to_global(lists, rows, status, len(g.pair_idx))
+        # fusion bands
+        yx = (g.true_yx - g.true_yx.min(axis=0)).astype(np.int32)
+        mh, mw = int(yx[:, 0].max()) + 128, int(yx[:, 1].max()) + 128
+        r0, r1 = mdist.shard_mosaic_rows(mh, world, rank, align=64)
+        use = mdist.tiles_touching_rows(yx[:, 0], 128, r0, r1)
+        band = ofu.fuse_overwrite(g.tiles[use], yx[use], np.zeros(len(use), dtype=int), 1, mh, mw)[0, r0:r1]
+        q.put((rank, g_rows.numpy(), g_st.numpy(), (r0, r1), band, sorted(local_tiles)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_gather():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = synth.make_grid(5, 3, 3, 128, 128, overlap=0.15, jitter=2)
+    ref, ref_st = oreg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 32, polish=False)
+    for rank, rows, st, _, _, _ in got:
+        assert np.array_equal(rows, ref) and np.array_equal(st, ref_st)  # every rank holds every pair
+    assert np.array_equal(ref[:, 1:].astype(np.int64), g.expected_shift)
+    # rank 0 owns grid rows 0-1 (tiles 0..5); rank 1 owns row 2 plus the halo row above it
+    assert got[0][5] == [0, 1, 2, 3, 4, 5] and got[1][5] == [3, 4, 5, 6, 7, 8]
+    yx = (g.true_yx - g.true_yx.min(axis=0)).astype(np.int32)
+    mh, mw = int(yx[:, 0].max()) + 128, int(yx[:, 1].max()) + 128
+    full = ofu.fuse_overwrite(g.tiles, yx, np.zeros(9, dtype=int), 1, mh, mw)[0]
+    stitched = np.concatenate([b for _, _, _, _, b, _ in got])
+    assert got[0][3][1] == got[1][3][0] and got[1][3][1] == mh
+    assert np.array_equal(stitched, full)
+
+
+def test_band_helpers():
+    assert [mdist.band_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [mdist.shard_mosaic_rows(37065, 8, r, align=2048) for r in range(8)][-1][1] == 37065
+    bands = [mdist.shard_mosaic_rows(37065, 8, r, align=2048) for r in range(8)]
+    assert all(a[1] == b[0] for a, b in zip(bands[:-1], bands[1:])) and bands[0][0] == 0
+    pair_idx, _ = synth.grid_pairs(20, 20)
+    sizes = [len(mdist.shard_pairs_by_grid_rows(pair_idx, 20, 20, 8, r)[0]) for r in range(8)]
+    assert sum(sizes) == 760 and max(sizes) - min(sizes) <= 39
