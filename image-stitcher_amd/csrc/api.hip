@@ -30,6 +30,7 @@ extern "C" int mistitch_destroy(mistitch_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->desc, &ctx->staging, &ctx->spectrum, &ctx->partial, &ctx->peaks,
                     &ctx->cand, &ctx->acc,     &ctx->misc,     &ctx->bins};
   for (DevBuf* b : bufs) b->release();
+  for (void* q : ctx->shape_allocs) (void)hipFree(q);
   ctx->prof.destroy();
   delete ctx;
   return MISTITCH_OK;

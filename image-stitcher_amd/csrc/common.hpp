@@ -148,5 +148,7 @@ struct mistitch_ctx {
   mistitch::DevBuf desc, staging, spectrum, partial, peaks, cand, acc, misc, bins;
   std::vector<char> host_scratch;
   std::set<const void*> lds_enabled;  // kernels already granted large dynamic LDS
+  std::map<long long, std::vector<char>> shapes;  // cached per-strip-shape launch configuration
+  std::vector<void*> shape_allocs;                // device tables owned by those configurations
   mistitch::Profiler prof;
 };

@@ -82,6 +82,38 @@ __device__ __forceinline__ void fetch_window(const uint16_t* src, const void* ff
   }
 }
 
+// One wave per output block lists, in placement order, the tiles that touch it:
+// bins[block][0] = how many (may exceed kMaxCand: the fuse kernel then scans every
+// tile), bins[block][1..] = the first kMaxCand tile indices.
+// grid = ceil(n_blocks / 4) workgroups of 4 waves; blocks are numbered as k_fuse's grid.
+__global__ __launch_bounds__(256) void k_fuse_bins(int n_tiles, int H, int W, const int32_t* __restrict__ tile_yx,
+                                                   const int32_t* __restrict__ tile_plane, int32_t* __restrict__ bins,
+                                                   int gx, int gy, int n_planes, int Wm, int row0, int row1) {
+  const int lane = threadIdx.x & 63;
+  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blk >= (int64_t)gx * gy * n_planes) return;
+  const int bx = (int)(blk % gx), by = (int)((blk / gx) % gy), plane = (int)(blk / ((int64_t)gx * gy));
+  const int x0 = bx * kBW, x1 = min(x0 + kBW, Wm);
+  const int y0 = row0 + by * kBH, y1 = min(y0 + kBH, row1);
+  int32_t* bin = bins + blk * (kMaxCand + 1);
+  int count = 0;
+  for (int base = 0; base < n_tiles; base += 64) {
+    const int t = base + lane;
+    bool hit = false;
+    if (t < n_tiles && tile_plane[t] == plane) {
+      const int ty = tile_yx[2 * t], tx = tile_yx[2 * t + 1];
+      hit = ty < y1 && ty + H > y0 && tx < x1 && tx + W > x0;
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (hit) {
+      const int slot = count + __popcll(mask & ((1ull << lane) - 1ull));
+      if (slot < kMaxCand) bin[1 + slot] = t;
+    }
+    count += __popcll(mask);
+  }
+  if (lane == 0) bin[0] = count;
+}
+
 // grid (ceil(Wm / kBW), ceil((row1 - row0) / kBH), n_planes)
 template <int MODE, int FF>
 __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restrict__ tiles, int n_tiles, int H,
@@ -90,44 +122,22 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
                                                        const int32_t* __restrict__ tile_plane,
                                                        const void* __restrict__ flatfields,
                                                        const int32_t* __restrict__ tile_ff,
+                                                       const int32_t* __restrict__ bins,
                                                        uint16_t* __restrict__ mosaic, int Hm, int Wm, int row0,
                                                        int row1) {
   __shared__ TileRef list[kMaxCand];
-  __shared__ int wave_count[kFuseThreads / 64];
-  __shared__ int total;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int plane = blockIdx.z;
   const int x0 = blockIdx.x * kBW, x1 = min(x0 + kBW, Wm);
   const int y0 = row0 + blockIdx.y * kBH, y1 = min(y0 + kBH, row1);
-  if (tid == 0) total = 0;
-  __syncthreads();
-  // ---- collect the tiles touching this block, preserving placement order ----
-  for (int base = 0; base < n_tiles; base += kFuseThreads) {
-    const int t = base + tid;
-    bool hit = false;
-    int ty = 0, tx = 0;
-    if (t < n_tiles && tile_plane[t] == plane) {
-      ty = tile_yx[2 * t];
-      tx = tile_yx[2 * t + 1];
-      hit = ty < y1 && ty + H > y0 && tx < x1 && tx + W > x0;
-    }
-    const unsigned long long mask = __ballot(hit);
-    if (lane == 0) wave_count[wave] = __popcll(mask);
-    __syncthreads();
-    int before = total;
-    for (int w = 0; w < wave; ++w) before += wave_count[w];
-    if (hit) {
-      const int slot = before + __popcll(mask & ((1ull << lane) - 1ull));
-      if (slot < kMaxCand) list[slot] = TileRef{ty, tx, t, tile_ff ? tile_ff[t] : -1};
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int add = 0;
-      for (int w = 0; w < kFuseThreads / 64; ++w) add += wave_count[w];
-      total += add;
-    }
-    __syncthreads();
+  // the tiles touching this block, in placement order, were listed by k_fuse_bins
+  const int32_t* bin = bins + ((int64_t)(plane * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (kMaxCand + 1);
+  const int total = bin[0];
+  if (tid < total && tid < kMaxCand) {
+    const int t = bin[1 + tid];
+    list[tid] = TileRef{tile_yx[2 * t], tile_yx[2 * t + 1], t, tile_ff ? tile_ff[t] : -1};
   }
+  __syncthreads();
   const int ncand_all = total;
   const bool overflow = ncand_all > kMaxCand;  // fall back to scanning every tile per window
   const int ncand = overflow ? n_tiles : ncand_all;
@@ -290,11 +300,10 @@ __global__ __launch_bounds__(256) void k_mip(const uint16_t* __restrict__ in, in
 
 template <int MODE, int FF>
 static void launch_fuse(mistitch_ctx* ctx, dim3 grid, const uint16_t* tiles, int n_tiles, int H, int W, int64_t pitch,
-                        const int32_t* yx, const int32_t* plane, const void* ffs, const int32_t* tff, uint16_t* mosaic,
-                        int Hm, int Wm, int row0, int row1) {
+                        const int32_t* yx, const int32_t* plane, const void* ffs, const int32_t* tff,
+                        const int32_t* bins, uint16_t* mosaic, int Hm, int Wm, int row0, int row1) {
   MS_LAUNCH(ctx, MODE == MISTITCH_FUSE_OVERWRITE ? "k_fuse_overwrite" : "k_fuse_feather", (k_fuse<MODE, FF>), grid,
-            dim3(kFuseThreads), 0, tiles, n_tiles, H, W, pitch, yx, plane, ffs,
-                     tff, mosaic, Hm, Wm, row0, row1);
+            dim3(kFuseThreads), 0, tiles, n_tiles, H, W, pitch, yx, plane, ffs, tff, bins, mosaic, Hm, Wm, row0, row1);
 }
 
 }  // namespace mistitch
@@ -322,9 +331,16 @@ extern "C" int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_til
   MS_HIP(hipSetDevice(ctx->device));
   const dim3 grid((mosaic_w + kBW - 1) / kBW, (row1 - row0 + kBH - 1) / kBH, n_planes);
   MS_REQUIRE(grid.y <= 65535, MISTITCH_ERR_UNSUPPORTED, "row band too tall for one launch");
+  const int64_t n_blocks = (int64_t)grid.x * grid.y * grid.z;
+  int rc;
+  if ((rc = ctx->bins.reserve((size_t)n_blocks * (kMaxCand + 1) * sizeof(int32_t)))) return rc;
+  const int32_t* bins = reinterpret_cast<const int32_t*>(ctx->bins.ptr);
+  MS_LAUNCH(ctx, "k_fuse_bins", k_fuse_bins, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, n_tiles, tile_h, tile_w,
+            tile_yx, tile_plane, reinterpret_cast<int32_t*>(ctx->bins.ptr), (int)grid.x, (int)grid.y, n_planes, mosaic_w,
+            row0, row1);
 #define MS_FUSE(M, F)                                                                                          \
   launch_fuse<M, F>(ctx, grid, tiles, n_tiles, tile_h, tile_w, tile_pitch, tile_yx, tile_plane, flatfields, tile_ff, \
-                    mosaic, mosaic_h, mosaic_w, row0, row1)
+                    bins, mosaic, mosaic_h, mosaic_w, row0, row1)
   if (mode == MISTITCH_FUSE_OVERWRITE) {
     if (ff_type == MISTITCH_FF_NONE) MS_FUSE(MISTITCH_FUSE_OVERWRITE, MISTITCH_FF_NONE);
     else if (ff_type == MISTITCH_FF_F32) MS_FUSE(MISTITCH_FUSE_OVERWRITE, MISTITCH_FF_F32);

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cmath>
 #include <limits>
+#include <set>
 
 #include "common.hpp"
 #include "fft.hpp"
@@ -54,6 +55,14 @@ struct Cand {
   int flag;    // 0 evaluate, 1 empty overlap (skipped), 2 fewer than 25 pixels, 3 duplicate
   int dup_of;  // index of the earlier identical candidate when flag == 3
 };
+
+// Rows of the intermediate spectrum are kept 128 bytes longer than L: with a
+// power-of-two pitch every row of a column block maps to the same few cache
+// sets and memory channels, and the column passes run several times slower.
+template <typename T>
+__host__ __device__ __forceinline__ int spectrum_pitch(int L) {
+  return L + 128 / (int)(2 * sizeof(T));
+}
 
 __device__ __forceinline__ bool peak_better(double v, int k, double bv, int bk) {
   return (v > bv) || (v == bv && k > bk);
@@ -247,15 +256,31 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
   LineAddr<T> addr{LineAddr<T>::padded(L) + 1};
   const int s0 = blockIdx.x * NF;
   if constexpr (VEC) {
-    for (int e = tid * 8; e < NF * L; e += kThreads * 8) {
-      const int f = e / L, i = e - f * L;
-      const uint4 va = *reinterpret_cast<const uint4*>(d.a + (int64_t)(s0 + f) * d.pitch + i);
-      const uint4 vb = *reinterpret_cast<const uint4*>(d.b + (int64_t)(s0 + f) * d.pitch + i);
-      const unsigned wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w};
+    constexpr int U = 2;  // 16-byte loads of both strips in flight before the first LDS write
+    for (int e0 = tid * 8; e0 < NF * L; e0 += kThreads * 8 * U) {
+      uint4 va[U], vb[U];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        buf[addr(f, i + 2 * q)] = mk<T>((T)(wa[q] & 0xffffu), (T)(wb[q] & 0xffffu));
-        buf[addr(f, i + 2 * q + 1)] = mk<T>((T)(wa[q] >> 16), (T)(wb[q] >> 16));
+      for (int u = 0; u < U; ++u) {
+        // out-of-range lanes re-read the last group instead of branching: a branch
+        // around a load makes the compiler drain the memory pipe at every join
+        const int e = min(e0 + u * kThreads * 8, NF * L - 8);
+        const int f = e / L, i = e - f * L;
+        va[u] = *reinterpret_cast<const uint4*>(d.a + (int64_t)(s0 + f) * d.pitch + i);
+        vb[u] = *reinterpret_cast<const uint4*>(d.b + (int64_t)(s0 + f) * d.pitch + i);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep every load ahead of the first LDS write
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * kThreads * 8;
+        if (e < NF * L) {
+          const int f = e / L, i = e - f * L;
+          const unsigned wa[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, wb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            buf[addr(f, i + 2 * q)] = mk<T>((T)(wa[q] & 0xffffu), (T)(wb[q] & 0xffffu));
+            buf[addr(f, i + 2 * q + 1)] = mk<T>((T)(wa[q] >> 16), (T)(wb[q] >> 16));
+          }
+        }
       }
     }
   } else {
@@ -266,10 +291,11 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
   }
   __syncthreads();
   fft_forward<T>(buf, addr, NF, planL, tid, kThreads);
-  cx<T>* out = spectrum + ((int64_t)blockIdx.y * S + s0) * L;
+  const int Lp = spectrum_pitch<T>(L);
+  cx<T>* out = spectrum + ((int64_t)blockIdx.y * S + s0) * Lp;
   for (int e = tid; e < NF * L; e += kThreads) {
     const int f = e / L, i = e - f * L;
-    out[(int64_t)f * L + i] = buf[addr(f, i)];
+    out[(int64_t)f * Lp + i] = buf[addr(f, i)];
   }
 }
 
@@ -284,13 +310,20 @@ __device__ __forceinline__ float cabs_safe<float>(float x, float y) {
   return hypotf(x, y);  // products of two 2^33 sums overflow float when squared
 }
 
+// A unit of the column pass: the storage positions [a0, a0 + na) whose results
+// are computed and written back, plus the positions [b0, b0 + nb) that hold their
+// negated frequencies (nb = 0 when the first range is closed under negation).
+struct CpsUnit {
+  int a0, na, b0, nb;
+};
+
 // Short-axis FFT, cross-power spectrum, short-axis inverse FFT.
-// grid (L / C, pairs_in_pass): one block of C adjacent storage positions plus
-// the block that holds their negated frequencies.
+// grid (n_units, pairs_in_pass).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc, const int8_t* status,
                                                             int pair0, int S, int L, int want_transposed,
-                                                            FftPlanDev planS, FftPlanDev planL, int C,
+                                                            FftPlanDev planS, FftPlanDev planL,
+                                                            const CpsUnit* __restrict__ units, int rs,
                                                             cx<T>* spectrum, T eps) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
@@ -300,28 +333,43 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
     const PairDesc& d = desc[p];
     if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
   }
-  const int b = blockIdx.x;
-  const int mb = planL.mpos[b * C] / C;
-  if (mb < b) return;  // the partner block owns this pair of blocks
-  const bool self = (mb == b);
-  const int ncol = self ? C : 2 * C;
-  const int rs = 2 * C;
+  const CpsUnit un = units[blockIdx.x];
+  const int na = un.na, ncol = un.na + un.nb;
   const int tid = threadIdx.x;
-  cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * L;
-  for (int e = tid; e < S * ncol; e += kThreads) {
-    const int s = e / ncol, c = e - s * ncol;
-    const int pos = c < C ? b * C + c : mb * C + (c - C);
-    buf[s * rs + c] = Z[(int64_t)s * L + pos];
+  const int Lp = spectrum_pitch<T>(L);
+  cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
+  {
+    constexpr int U = 8;  // loads in flight per lane before the first LDS write
+    for (int e0 = tid; e0 < S * ncol; e0 += kThreads * U) {
+      cx<T> r[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = min(e0 + u * kThreads, S * ncol - 1);  // clamp, do not branch around the load
+        const int s = e / ncol, c = e - s * ncol;
+        const int pos = c < na ? un.a0 + c : un.b0 + (c - na);
+        r[u] = Z[(int64_t)s * Lp + pos];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep every load ahead of the first LDS write
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * kThreads;
+        if (e < S * ncol) {
+          const int s = e / ncol, c = e - s * ncol;
+          buf[s * rs + c] = r[u];
+        }
+      }
+    }
   }
   __syncthreads();
   ColAddr<T> addr{rs};
   fft_forward<T>(buf, addr, ncol, planS, tid, kThreads);
-  for (int e = tid; e < S * C; e += kThreads) {
-    const int q = e / C, c = e - q * C;
-    const int mp = planL.mpos[b * C + c];
-    const int pc = self ? (mp - b * C) : (C + mp - mb * C);
+  for (int e = tid; e < S * na; e += kThreads) {
+    const int q = e / na, c = e - q * na;
+    const int mp = planL.mpos[un.a0 + c];
+    const bool partner_in_a = mp >= un.a0 && mp < un.a0 + na;
+    const int pc = partner_in_a ? (mp - un.a0) : (na + mp - un.b0);
     const int q2 = planS.mpos[q];
-    if (self && (q2 * rs + pc) < (q * rs + c)) continue;  // the partner cell's owner writes both
+    if (partner_in_a && (q2 * rs + pc) < (q * rs + c)) continue;  // the partner cell's owner writes both
     const cx<T> z = buf[q * rs + c];
     const cx<T> zm = buf[q2 * rs + pc];
     // z = A + iB with A, B the spectra of the two real strips:
@@ -334,13 +382,13 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
     fx *= inv;
     fy *= inv;
     buf[q * rs + c] = mk<T>(fx, fy);
-    if (self && (q2 * rs + pc) != (q * rs + c)) buf[q2 * rs + pc] = mk<T>(fx, -fy);
+    if (partner_in_a && (q2 * rs + pc) != (q * rs + c)) buf[q2 * rs + pc] = mk<T>(fx, -fy);
   }
   __syncthreads();
-  fft_inverse<T>(buf, addr, C, planS, tid, kThreads);
-  for (int e = tid; e < S * C; e += kThreads) {
-    const int s = e / C, c = e - s * C;
-    Z[(int64_t)s * L + b * C + c] = buf[s * rs + c];
+  fft_inverse<T>(buf, addr, na, planS, tid, kThreads);
+  for (int e = tid; e < S * na; e += kThreads) {
+    const int s = e / na, c = e - s * na;
+    Z[(int64_t)s * Lp + un.a0 + c] = buf[s * rs + c];
   }
 }
 
@@ -349,8 +397,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc, const int8_t* status,
                                                            int pair0, int S, int L, int want_transposed,
-                                                           FftPlanDev planL, int C, int NF,
-                                                           const cx<T>* spectrum, int k, Peak* partial,
+                                                           FftPlanDev planL, const uint16_t* __restrict__ srcpos,
+                                                           int NF, const cx<T>* spectrum, int k, Peak* partial,
                                                            int partial_stride, double* pcm_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
@@ -362,19 +410,36 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   const int tid = threadIdx.x;
   LineAddr<T> addr{LineAddr<T>::padded(L) + 1};
   const int s0 = blockIdx.x * NF * 2;
-  const cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * L;
-  for (int e = tid; e < NF * L; e += kThreads) {
-    const int f = e / L, pos = e - f * L;
-    const int bp = pos / C;
-    const bool stored = (planL.mpos[bp * C] / C) >= bp;
-    const int src = stored ? pos : planL.mpos[pos];
-    cx<T> g1 = Z[(int64_t)(s0 + 2 * f) * L + src];
-    cx<T> g2 = Z[(int64_t)(s0 + 2 * f + 1) * L + src];
-    if (!stored) {
-      g1.y = -g1.y;
-      g2.y = -g2.y;
+  const int Lp = spectrum_pitch<T>(L);
+  const cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
+  {
+    constexpr int U = 4;  // two loads per element: 8 in flight per lane
+    for (int e0 = tid; e0 < NF * L; e0 += kThreads * U) {
+      cx<T> g1[U], g2[U];
+      bool conj[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = min(e0 + u * kThreads, NF * L - 1);  // clamp, do not branch around the loads
+        const int f = e / L, pos = e - f * L;
+        const int src = srcpos[pos];  // where this frequency (or its conjugate partner) was stored
+        conj[u] = src != pos;
+        g1[u] = Z[(int64_t)(s0 + 2 * f) * Lp + src];
+        g2[u] = Z[(int64_t)(s0 + 2 * f + 1) * Lp + src];
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep every load ahead of the first LDS write
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * kThreads;
+        if (e < NF * L) {
+          const int f = e / L, pos = e - f * L;
+          if (conj[u]) {
+            g1[u].y = -g1[u].y;
+            g2[u].y = -g2[u].y;
+          }
+          buf[addr(f, pos)] = mk<T>(g1[u].x - g2[u].y, g1[u].y + g2[u].x);  // g1 + i g2
+        }
+      }
     }
-    buf[addr(f, pos)] = mk<T>(g1.x - g2.y, g1.y + g2.x);  // g1 + i g2
   }
   __syncthreads();
   fft_inverse<T>(buf, addr, NF, planL, tid, kThreads);
@@ -750,33 +815,61 @@ static int build_plan(mistitch_ctx* ctx, int n, bool f64, FftPlanDev* out) {
   return MISTITCH_OK;
 }
 
-// Largest block width C (power of two) such that the storage positions of the
-// negated frequencies of every aligned block of C positions form one aligned
-// block again, and the short-axis working set fits the LDS budget.
-static int choose_cps_block(const std::vector<uint16_t>& mpos, int L, int S, size_t esz, size_t lds_budget) {
-  int C = 16;
-  while (C > 1) {
-    bool ok = (C <= L) && ((size_t)S * 2 * C * esz <= lds_budget);
-    if (ok) {
-      for (int b = 0; b < L / C && ok; ++b) {
-        const int mb = mpos[b * C] / C;
-        for (int c = 1; c < C; ++c)
-          if (mpos[b * C + c] / C != mb) {
-            ok = false;
-            break;
-          }
-      }
+// Cut the storage positions of the long axis into column-pass units of (at most)
+// 2C columns: aligned blocks of C positions paired with the block holding their
+// negated frequencies, or merged into one self-contained range where negation
+// does not map block to block (the positions of the frequencies 0, M, 2M, ...).
+static bool build_units(const std::vector<uint16_t>& mpos, int L, int C, std::vector<CpsUnit>* units,
+                        std::vector<uint16_t>* srcpos) {
+  const int nb = L / C;
+  if (nb < 1) return false;
+  std::vector<char> done(nb, 0);
+  units->clear();
+  for (int b = 0; b < nb; ++b) {
+    if (done[b]) continue;
+    std::set<int> group{b};
+    bool grew = true;
+    while (grew) {
+      grew = false;
+      for (int g : std::vector<int>(group.begin(), group.end()))
+        for (int c = 0; c < C; ++c)
+          if (group.insert(mpos[g * C + c] / C).second) grew = true;
     }
-    if (ok) return C;
-    C >>= 1;
+    const int lo = *group.begin(), hi = *group.rbegin();
+    if (group.size() == 1) {
+      units->push_back(CpsUnit{b * C, C, 0, 0});
+    } else if (group.size() == 2) {
+      // two blocks: either each maps wholly onto the other (a pair) or they only close together
+      bool pair = true;
+      for (int c = 0; c < C; ++c) pair = pair && (mpos[lo * C + c] / C == hi);
+      if (pair)
+        units->push_back(CpsUnit{lo * C, C, hi * C, C});
+      else if (hi == lo + 1)
+        units->push_back(CpsUnit{lo * C, 2 * C, 0, 0});
+      else
+        return false;
+    } else {
+      return false;
+    }
+    for (int g : group) done[g] = 1;
   }
-  return 1;
+  srcpos->assign(L, 0);
+  std::vector<char> stored(L, 0);
+  for (const CpsUnit& u : *units)
+    for (int i = 0; i < u.na; ++i) stored[u.a0 + i] = 1;
+  for (int pos = 0; pos < L; ++pos) (*srcpos)[pos] = stored[pos] ? (uint16_t)pos : mpos[pos];
+  for (int pos = 0; pos < L; ++pos)
+    if (!stored[(*srcpos)[pos]]) return false;
+  return true;
 }
 
 struct ShapeCfg {
   int S, L;
   FftPlanDev planS, planL;
-  int C;       // columns per k_fft_short_cps block
+  int C;       // columns per block of the column pass (LDS rows hold 2C)
+  const CpsUnit* units;    // device
+  int n_units;
+  const uint16_t* srcpos;  // device: where k_fft_long_inv finds each frequency
   int NF_fwd;  // lines per k_fft_long_fwd block
   int NF_inv;  // line pairs per k_fft_long_inv block
   size_t lds_fwd, lds_cps, lds_inv;
@@ -794,6 +887,12 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   MS_REQUIRE(is_pow2(S) && is_pow2(L) && S >= 8 && L >= 8 && L <= 4096 && S <= 1024, MISTITCH_ERR_UNSUPPORTED,
              "strip %d x %d unsupported: sides must be powers of two, long side in [8, 4096], short side in [8, 1024]",
              S, L);
+  const long long key = (((long long)S << 20) | (long long)L) * 2 + (f64 ? 1 : 0);
+  auto it = ctx->shapes.find(key);
+  if (it != ctx->shapes.end()) {
+    memcpy(cfg, it->second.data(), sizeof(ShapeCfg));
+    return MISTITCH_OK;
+  }
   cfg->S = S;
   cfg->L = L;
   int rc = build_plan(ctx, S, f64, &cfg->planS);
@@ -803,9 +902,30 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   const size_t esz = f64 ? 16 : 8;
   std::vector<uint16_t> mpos(L);
   MS_HIP(hipMemcpy(mpos.data(), cfg->planL.mpos, (size_t)L * 2, hipMemcpyDeviceToHost));
-  cfg->C = choose_cps_block(mpos, L, S, esz, kLdsBudget);
-  cfg->lds_cps = (size_t)S * 2 * cfg->C * esz;
+  // widest column block whose units exist and whose working set leaves room for two blocks per CU
+  std::vector<CpsUnit> units;
+  std::vector<uint16_t> srcpos;
+  int C = 16;
+  for (; C >= 1; C >>= 1) {
+    if (C > L) continue;
+    if (C > 1 && (size_t)S * 2 * C * esz > kLdsBudget) continue;
+    if (build_units(mpos, L, C, &units, &srcpos)) break;
+  }
+  MS_REQUIRE(C >= 1, MISTITCH_ERR_UNSUPPORTED, "no column-pass decomposition for long side %d", L);
+  cfg->C = C;
+  cfg->lds_cps = (size_t)S * 2 * C * esz;
   MS_REQUIRE(cfg->lds_cps <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "short side %d needs %zu B of LDS", S, cfg->lds_cps);
+  {
+    const size_t ub = units.size() * sizeof(CpsUnit), sb = (size_t)L * sizeof(uint16_t);
+    void* blob = nullptr;
+    MS_HIP(hipMalloc(&blob, ub + sb));
+    ctx->shape_allocs.push_back(blob);
+    MS_HIP(hipMemcpy(blob, units.data(), ub, hipMemcpyHostToDevice));
+    MS_HIP(hipMemcpy(reinterpret_cast<char*>(blob) + ub, srcpos.data(), sb, hipMemcpyHostToDevice));
+    cfg->units = reinterpret_cast<const CpsUnit*>(blob);
+    cfg->n_units = (int)units.size();
+    cfg->srcpos = reinterpret_cast<const uint16_t*>(reinterpret_cast<char*>(blob) + ub);
+  }
   const size_t lb = f64 ? line_bytes<double>(L) : line_bytes<float>(L);
   int nf = (int)(kLdsBudget / lb);
   if (nf < 1) nf = 1;
@@ -818,6 +938,9 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   cfg->lds_fwd = lb * cfg->NF_fwd;
   cfg->lds_inv = lb * cfg->NF_inv;
   MS_REQUIRE(cfg->lds_fwd <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "long side %d needs %zu B of LDS", L, cfg->lds_fwd);
+  std::vector<char> blob(sizeof(ShapeCfg));
+  memcpy(blob.data(), cfg, sizeof(ShapeCfg));
+  ctx->shapes[key] = blob;
   return MISTITCH_OK;
 }
 
@@ -880,11 +1003,11 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
   }
   if ((rc = allow_lds(ctx, k_fft_short_cps<T>, cfg.lds_cps))) return rc;
   const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
-  MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<T>), dim3(cfg.L / cfg.C, n), dim3(kThreads), cfg.lds_cps, ws.desc, status,
-                     pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.C, spec, eps);
+  MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<T>), dim3(cfg.n_units, n), dim3(kThreads), cfg.lds_cps, ws.desc, status,
+            pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, spec, eps);
   if ((rc = allow_lds(ctx, k_fft_long_inv<T>, cfg.lds_inv))) return rc;
   MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv<T>), dim3(cfg.S / (2 * cfg.NF_inv), n), dim3(kThreads), cfg.lds_inv, ws.desc,
-                     status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.C, cfg.NF_inv, spec, k, ws.partial,
+                     status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.srcpos, cfg.NF_inv, spec, k, ws.partial,
                      ws.partial_stride, pcm_out);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
@@ -909,7 +1032,7 @@ extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int 
   if ((rc = make_shape(ctx, w_left, tile_h, f64, &a))) return rc;
   if ((rc = make_shape(ctx, w_top, tile_w, f64, &b))) return rc;
   const size_t esz = f64 ? 16 : 8;
-  const size_t spec = std::max((size_t)a.S * a.L, (size_t)b.S * b.L) * esz;
+  const size_t spec = std::max((size_t)a.S * (a.L + 128 / esz), (size_t)b.S * (b.L + 128 / esz)) * esz;
   const int pstride = std::max(a.S / (2 * a.NF_inv), b.S / (2 * b.NF_inv)) * kMaxK;
   const int chunk = max_pairs < ctx->pair_chunk ? max_pairs : ctx->pair_chunk;
   RegWorkspace ws;
@@ -937,7 +1060,8 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
   if ((rc = make_shape(ctx, w_top, W, f64, &cfg_top))) return rc;
   const bool same_shape = cfg_left.S == cfg_top.S && cfg_left.L == cfg_top.L;
   const size_t esz = f64 ? 16 : 8;
-  const size_t spec = std::max((size_t)cfg_left.S * cfg_left.L, (size_t)cfg_top.S * cfg_top.L) * esz;
+  const size_t spec =
+      std::max((size_t)cfg_left.S * (cfg_left.L + 128 / esz), (size_t)cfg_top.S * (cfg_top.L + 128 / esz)) * esz;
   const int pstride = std::max(cfg_left.S / (2 * cfg_left.NF_inv), cfg_top.S / (2 * cfg_top.NF_inv)) * kMaxK;
   const int chunk = n_pairs < ctx->pair_chunk ? n_pairs : ctx->pair_chunk;
   RegWorkspace ws;
@@ -997,7 +1121,7 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   const size_t esz = f64 ? 16 : 8;
   const int pstride = (cfg.S / (2 * cfg.NF_inv)) * kMaxK;
   RegWorkspace ws;
-  if ((rc = reserve_registration(ctx, 1, 1, (size_t)S * L, (size_t)S * L * esz, pstride, &ws))) return rc;
+  if ((rc = reserve_registration(ctx, 1, 1, (size_t)S * L, (size_t)S * (L + 128 / esz) * esz, pstride, &ws))) return rc;
   if ((rc = ctx->misc.reserve(256))) return rc;
   hipStream_t st = ctx->stream;
   PairDesc d;
