@@ -15,7 +15,7 @@ from typing import Optional
 import torch  # noqa: F401  (import order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmistitch.so")
+LIB_PATH = os.environ.get("MISTITCH_LIB") or os.path.join(_HERE, "libmistitch.so")  # override: kernel experiments
 
 OK = 0
 ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM = -1, -2, -3, -4
