@@ -143,7 +143,7 @@ struct Profiler {
 struct mistitch_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
-  int pair_chunk = 32;  // pairs processed per pipeline pass (bounds the FFT workspace)
+  int pair_chunk = 128;  // pairs processed per pipeline pass (bounds the FFT workspace)
   std::map<long long, mistitch::FftPlanHost> plans;  // key = n * 2 + (is_f64)
   mistitch::DevBuf desc, staging, spectrum, partial, peaks, cand, acc, misc, bins;
   std::vector<char> host_scratch;

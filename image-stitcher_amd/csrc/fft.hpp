@@ -147,11 +147,44 @@ struct ColAddr {
   }
 };
 
+// Twiddle factors exp(-2 pi i k / N) come from two small LDS tables,
+// w^k = hi[k >> 6] * lo[k & 63], and their powers from a short product tree: a
+// pass then needs one lookup per butterfly instead of R - 1 global loads whose
+// latency nothing in a barrier-separated pass could hide.
+template <typename T>
+struct Twiddles {
+  const cx<T>* lo;  // w^k, k < 64
+  const cx<T>* hi;  // w^(64 k), k < max(N / 64, 1)
+  __device__ __forceinline__ cx<T> get(int k) const { return k < 64 ? lo[k] : cmul(hi[k >> 6], lo[k & 63]); }
+  static __host__ __device__ __forceinline__ int entries(int n) { return 64 + (n >= 64 ? n / 64 : 1); }
+};
+
+// Fill the two tables (entries(plan.n) elements at dst); caller synchronises.
+template <typename T>
+__device__ __forceinline__ Twiddles<T> load_twiddles(cx<T>* dst, const FftPlanDev& plan, int tid, int nthr) {
+  const cx<T>* tw = reinterpret_cast<const cx<T>*>(plan.tw);
+  const int n_hi = plan.n >= 64 ? plan.n / 64 : 1;
+  for (int k = tid; k < 64 + n_hi; k += nthr) {
+    int src = k < 64 ? k : (k - 64) * 64;
+    if (src >= plan.n) src = 0;
+    dst[k] = tw[src];
+  }
+  return Twiddles<T>{dst, dst + 64};
+}
+
+// w[d] = base^d for d = 1 .. R-1 (squarings for even d, one extra product for odd d).
+template <typename T, int R>
+__device__ __forceinline__ void twiddle_powers(cx<T> base, cx<T> (&w)[R]) {
+  w[1] = base;
+#pragma unroll
+  for (int d = 2; d < R; ++d) w[d] = (d & 1) ? cmul(w[d - 1], base) : cmul(w[d / 2], w[d / 2]);
+}
+
 // One radix-R pass over nfft transforms of length N whose current sub-block
-// length is n (n = N on the first forward pass).  tw holds N entries.
+// length is n (n = N on the first forward pass).
 template <typename T, int R, bool INV, class Addr>
 __device__ __forceinline__ void fft_pass(cx<T>* buf, const Addr& addr, int nfft, int N, int n,
-                                         const cx<T>* __restrict__ tw, int tid, int nthr) {
+                                         const Twiddles<T>& tw, int tid, int nthr) {
   const int per = N / R;
   const int sub = n / R;
   const int twstep = N / n;
@@ -167,13 +200,17 @@ __device__ __forceinline__ void fft_pass(cx<T>* buf, const Addr& addr, int nfft,
     if constexpr (!INV) {
       Dft<T, R, false>::run(v);
       if (sub > 1) {
+        cx<T> pw[R];
+        twiddle_powers<T, R>(tw.get(j * twstep), pw);
 #pragma unroll
-        for (int d = 1; d < R; ++d) v[d] = cmul(v[d], tw[j * d * twstep]);
+        for (int d = 1; d < R; ++d) v[d] = cmul(v[d], pw[d]);
       }
     } else {
       if (sub > 1) {
+        cx<T> pw[R];
+        twiddle_powers<T, R>(tw.get(j * twstep), pw);
 #pragma unroll
-        for (int d = 1; d < R; ++d) v[d] = cmulc(v[d], tw[j * d * twstep]);
+        for (int d = 1; d < R; ++d) v[d] = cmulc(v[d], pw[d]);
       }
       Dft<T, R, true>::run(v);
     }
@@ -184,7 +221,7 @@ __device__ __forceinline__ void fft_pass(cx<T>* buf, const Addr& addr, int nfft,
 
 template <typename T, bool INV, class Addr>
 __device__ __forceinline__ void fft_dispatch(int radix, cx<T>* buf, const Addr& addr, int nfft, int N,
-                                             int n, const cx<T>* __restrict__ tw, int tid, int nthr) {
+                                             int n, const Twiddles<T>& tw, int tid, int nthr) {
   switch (radix) {
     case 16: fft_pass<T, 16, INV>(buf, addr, nfft, N, n, tw, tid, nthr); break;
     case 8: fft_pass<T, 8, INV>(buf, addr, nfft, N, n, tw, tid, nthr); break;
@@ -194,11 +231,11 @@ __device__ __forceinline__ void fft_dispatch(int radix, cx<T>* buf, const Addr& 
 }
 
 // Forward transform of nfft sequences held in LDS.  Caller must have
-// synchronised after filling buf; returns with the block synchronised.
+// synchronised after filling buf and the twiddle tables; returns with the block
+// synchronised.
 template <typename T, class Addr>
-__device__ __forceinline__ void fft_forward(cx<T>* buf, const Addr& addr, int nfft,
-                                            const FftPlanDev& plan, int tid, int nthr) {
-  const cx<T>* tw = reinterpret_cast<const cx<T>*>(plan.tw);
+__device__ __forceinline__ void fft_forward(cx<T>* buf, const Addr& addr, int nfft, const FftPlanDev& plan,
+                                            const Twiddles<T>& tw, int tid, int nthr) {
   int n = plan.n;
   for (int i = 0; i < plan.npass; ++i) {
     fft_dispatch<T, false>(plan.radix[i], buf, addr, nfft, plan.n, n, tw, tid, nthr);
@@ -209,9 +246,8 @@ __device__ __forceinline__ void fft_forward(cx<T>* buf, const Addr& addr, int nf
 
 // Unnormalised inverse transform (digit-reversed in, natural out).
 template <typename T, class Addr>
-__device__ __forceinline__ void fft_inverse(cx<T>* buf, const Addr& addr, int nfft,
-                                            const FftPlanDev& plan, int tid, int nthr) {
-  const cx<T>* tw = reinterpret_cast<const cx<T>*>(plan.tw);
+__device__ __forceinline__ void fft_inverse(cx<T>* buf, const Addr& addr, int nfft, const FftPlanDev& plan,
+                                            const Twiddles<T>& tw, int tid, int nthr) {
   int n = 1;
   for (int i = plan.npass - 1; i >= 0; --i) {
     n *= plan.radix[i];

@@ -225,6 +225,49 @@ __global__ void k_transpose_strips(const uint16_t* tiles, int64_t tile_pitch, in
   }
 }
 
+// Same for strips whose sides are multiples of 64 and whose rows are 16-byte
+// aligned: 64 x 64 tiles, 16 bytes per lane in and out.
+// grid (L / 64, S / 64, 2 * pairs_in_pass), block 256.
+__global__ __launch_bounds__(256) void k_transpose_strips64(const uint16_t* tiles, int64_t tile_pitch, int H, int W,
+                                                            int w_left, const int32_t* pair_idx, const PairDesc* desc,
+                                                            const int8_t* status, int pair0) {
+  __shared__ uint16_t tile[64][64 + 2];
+  const int p = pair0 + (blockIdx.z >> 1), which = blockIdx.z & 1;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  if (!d.transposed) return;
+  const uint16_t* src = tiles + (int64_t)pair_idx[2 * p + which] * tile_pitch + (which == 0 ? W - w_left : 0);
+  uint16_t* dst = const_cast<uint16_t*>(which == 0 ? d.a : d.b);
+  const int l0 = blockIdx.x * 64, s0 = blockIdx.y * 64;
+  const int t = threadIdx.x, sub = t & 7, row = t >> 3;  // 8 lanes cover one 128-byte row segment
+  uint4 v[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+    v[i] = *reinterpret_cast<const uint4*>(src + (int64_t)(l0 + row + 32 * i) * W + s0 + 8 * sub);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned w4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+    unsigned* dstw = reinterpret_cast<unsigned*>(&tile[row + 32 * i][8 * sub]);  // rows are 132 bytes: 4-byte aligned
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dstw[q] = w4[q];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int s = row + 32 * i;  // output line
+    unsigned w4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      w4[q] = (unsigned)tile[8 * sub + 2 * q][s] | ((unsigned)tile[8 * sub + 2 * q + 1][s] << 16);
+    uint4 o;
+    o.x = w4[0];
+    o.y = w4[1];
+    o.z = w4[2];
+    o.w = w4[3];
+    *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + s) * H + l0 + 8 * sub) = o;
+  }
+}
+
 // Generic transposing copy used by the single-strip entry points (tall strips).
 __global__ void k_transpose_plain(const uint16_t* src, int64_t pitch, int h, int w, uint16_t* dst) {
   __shared__ uint16_t tile[32][33];
@@ -254,6 +297,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
   if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
   const int tid = threadIdx.x;
   LineAddr<T> addr{LineAddr<T>::padded(L) + 1};
+  const Twiddles<T> tw = load_twiddles<T>(buf + NF * addr.fstride, planL, tid, kThreads);
   const int s0 = blockIdx.x * NF;
   if constexpr (VEC) {
     constexpr int U = 2;  // 16-byte loads of both strips in flight before the first LDS write
@@ -290,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
     }
   }
   __syncthreads();
-  fft_forward<T>(buf, addr, NF, planL, tid, kThreads);
+  fft_forward<T>(buf, addr, NF, planL, tw, tid, kThreads);
   const int Lp = spectrum_pitch<T>(L);
   cx<T>* out = spectrum + ((int64_t)blockIdx.y * S + s0) * Lp;
   for (int e = tid; e < NF * L; e += kThreads) {
@@ -338,6 +382,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   const int tid = threadIdx.x;
   const int Lp = spectrum_pitch<T>(L);
   cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
+  const Twiddles<T> tw = load_twiddles<T>(buf + S * rs, planS, tid, kThreads);
   {
     constexpr int U = 8;  // loads in flight per lane before the first LDS write
     for (int e0 = tid; e0 < S * ncol; e0 += kThreads * U) {
@@ -362,7 +407,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   }
   __syncthreads();
   ColAddr<T> addr{rs};
-  fft_forward<T>(buf, addr, ncol, planS, tid, kThreads);
+  fft_forward<T>(buf, addr, ncol, planS, tw, tid, kThreads);
   for (int e = tid; e < S * na; e += kThreads) {
     const int q = e / na, c = e - q * na;
     const int mp = planL.mpos[un.a0 + c];
@@ -385,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
     if (partner_in_a && (q2 * rs + pc) != (q * rs + c)) buf[q2 * rs + pc] = mk<T>(fx, -fy);
   }
   __syncthreads();
-  fft_inverse<T>(buf, addr, na, planS, tid, kThreads);
+  fft_inverse<T>(buf, addr, na, planS, tw, tid, kThreads);
   for (int e = tid; e < S * na; e += kThreads) {
     const int s = e / na, c = e - s * na;
     Z[(int64_t)s * Lp + un.a0 + c] = buf[s * rs + c];
@@ -409,6 +454,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
   const int tid = threadIdx.x;
   LineAddr<T> addr{LineAddr<T>::padded(L) + 1};
+  const Twiddles<T> tw = load_twiddles<T>(buf + NF * addr.fstride, planL, tid, kThreads);
   const int s0 = blockIdx.x * NF * 2;
   const int Lp = spectrum_pitch<T>(L);
   const cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
@@ -442,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
     }
   }
   __syncthreads();
-  fft_inverse<T>(buf, addr, NF, planL, tid, kThreads);
+  fft_inverse<T>(buf, addr, NF, planL, tw, tid, kThreads);
   const double scale = 1.0 / ((double)S * (double)L);
   if (pcm_out != nullptr) {
     double* out = pcm_out + (int64_t)blockIdx.y * S * L;
@@ -555,6 +601,99 @@ __global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* d
   }
 }
 
+// Exact integer moments of two uint16 rows, 8 pixels per lane and step.  Pixels
+// are split into byte planes so that every product is a v_dot4_u32_u8; a lane can
+// take 16,000 steps before a 32-bit partial sum could wrap (callers stay far below).
+struct __attribute__((packed, aligned(2))) U16x8 {
+  unsigned d[4];
+};
+
+struct MomentAcc {
+  // byte-plane partial sums: l = low bytes, h = high bytes
+  unsigned a_l = 0, a_h = 0, b_l = 0, b_h = 0;
+  unsigned aa_ll = 0, aa_lh = 0, aa_hh = 0, bb_ll = 0, bb_lh = 0, bb_hh = 0;
+  unsigned ab_ll = 0, ab_x = 0, ab_hh = 0;
+  __device__ __forceinline__ void add4(unsigned a0, unsigned a1, unsigned b0, unsigned b1) {
+    const unsigned al = __builtin_amdgcn_perm(a1, a0, 0x06040200u), ah = __builtin_amdgcn_perm(a1, a0, 0x07050301u);
+    const unsigned bl = __builtin_amdgcn_perm(b1, b0, 0x06040200u), bh = __builtin_amdgcn_perm(b1, b0, 0x07050301u);
+    a_l = __builtin_amdgcn_udot4(al, 0x01010101u, a_l, false);
+    a_h = __builtin_amdgcn_udot4(ah, 0x01010101u, a_h, false);
+    b_l = __builtin_amdgcn_udot4(bl, 0x01010101u, b_l, false);
+    b_h = __builtin_amdgcn_udot4(bh, 0x01010101u, b_h, false);
+    aa_ll = __builtin_amdgcn_udot4(al, al, aa_ll, false);
+    aa_lh = __builtin_amdgcn_udot4(al, ah, aa_lh, false);
+    aa_hh = __builtin_amdgcn_udot4(ah, ah, aa_hh, false);
+    bb_ll = __builtin_amdgcn_udot4(bl, bl, bb_ll, false);
+    bb_lh = __builtin_amdgcn_udot4(bl, bh, bb_lh, false);
+    bb_hh = __builtin_amdgcn_udot4(bh, bh, bb_hh, false);
+    ab_ll = __builtin_amdgcn_udot4(al, bl, ab_ll, false);
+    ab_x = __builtin_amdgcn_udot4(al, bh, ab_x, false);
+    ab_x = __builtin_amdgcn_udot4(ah, bl, ab_x, false);
+    ab_hh = __builtin_amdgcn_udot4(ah, bh, ab_hh, false);
+  }
+  __device__ __forceinline__ void add8(const U16x8& a, const U16x8& b) {
+    add4(a.d[0], a.d[1], b.d[0], b.d[1]);
+    add4(a.d[2], a.d[3], b.d[2], b.d[3]);
+  }
+  // v[0..5) = sum a, sum b, sum a^2, sum b^2, sum ab
+  __device__ __forceinline__ void totals(unsigned long long (&v)[5]) const {
+    v[0] = (unsigned long long)a_l + ((unsigned long long)a_h << 8);
+    v[1] = (unsigned long long)b_l + ((unsigned long long)b_h << 8);
+    v[2] = (unsigned long long)aa_ll + ((unsigned long long)aa_lh << 9) + ((unsigned long long)aa_hh << 16);
+    v[3] = (unsigned long long)bb_ll + ((unsigned long long)bb_lh << 9) + ((unsigned long long)bb_hh << 16);
+    v[4] = (unsigned long long)ab_ll + ((unsigned long long)ab_x << 8) + ((unsigned long long)ab_hh << 16);
+  }
+};
+
+// Rows [r_begin, r_end) step r_step of two windows of ncols pixels; all 256 threads.
+__device__ __forceinline__ void moments_of_rows(const uint16_t* a, int64_t pa, const uint16_t* b, int64_t pb,
+                                                int r_begin, int r_end, int r_step, int ncols,
+                                                unsigned long long (&v)[5]) {
+  MomentAcc acc;
+  unsigned long long tail[5] = {0, 0, 0, 0, 0};
+  const int ngroups = ncols >> 3;
+  for (int r = r_begin; r < r_end; r += r_step) {
+    const uint16_t* ra = a + (int64_t)r * pa;
+    const uint16_t* rb = b + (int64_t)r * pb;
+    for (int g = threadIdx.x; g < ngroups; g += kThreads)
+      acc.add8(*reinterpret_cast<const U16x8*>(ra + 8 * g), *reinterpret_cast<const U16x8*>(rb + 8 * g));
+    const int e = 8 * ngroups + (int)threadIdx.x;
+    if (e < ncols) {
+      const unsigned long long x = ra[e], y = rb[e];
+      tail[0] += x;
+      tail[1] += y;
+      tail[2] += x * x;
+      tail[3] += y * y;
+      tail[4] += x * y;
+    }
+  }
+  acc.totals(v);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) v[i] += tail[i];
+}
+
+// Sum v[0..5) over the workgroup and add it to acc[0..5) with integer atomics
+// (exact and order independent).
+__device__ __forceinline__ void reduce_moments(unsigned long long (&v)[5], unsigned long long* red,
+                                               unsigned long long* acc) {
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) red[wave * 5 + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < 5) {
+    unsigned long long t = 0;
+    for (int w = 0; w < kThreads / 64; ++w) t += red[w * 5 + threadIdx.x];
+    atomicAdd(&acc[threadIdx.x], t);
+  }
+}
+
 // Exact moments (sum a, sum b, sum a^2, sum b^2, sum ab) over the overlap of a
 // candidate shift.  grid (kNccChunks, kNumCand, pairs_in_pass).
 __global__ __launch_bounds__(kThreads) void k_ncc_accumulate(const PairDesc* desc, const int8_t* status,
@@ -570,40 +709,11 @@ __global__ __launch_bounds__(kThreads) void k_ncc_accumulate(const PairDesc* des
   const int dl = d.transposed ? c.y : c.x;
   const int s_lo = ds > 0 ? ds : 0, s_hi = d.S + (ds < 0 ? ds : 0);
   const int l_lo = dl > 0 ? dl : 0, l_hi = d.L + (dl < 0 ? dl : 0);
-  const int ncols = l_hi - l_lo;
-  unsigned long long sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
-  for (int s = s_lo + blockIdx.x; s < s_hi; s += gridDim.x) {
-    const uint16_t* ra = d.a + (int64_t)s * d.pitch + l_lo;
-    const uint16_t* rb = d.b + (int64_t)(s - ds) * d.pitch + (l_lo - dl);
-    unsigned int ta = 0, tb = 0;  // a row holds at most 4096 values: sums fit 32 bits
-    for (int i = threadIdx.x; i < ncols; i += kThreads) {
-      const unsigned int va = ra[i], vb = rb[i];
-      ta += va;
-      tb += vb;
-      saa += (unsigned long long)va * va;
-      sbb += (unsigned long long)vb * vb;
-      sab += (unsigned long long)va * vb;
-    }
-    sa += ta;
-    sb += tb;
-  }
-  unsigned long long v[5] = {sa, sb, saa, sbb, sab};
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
-  }
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i) red[wave * 5 + i] = v[i];
-  }
-  __syncthreads();
-  if (threadIdx.x < 5) {
-    unsigned long long t = 0;
-    for (int w = 0; w < kThreads / 64; ++w) t += red[w * 5 + threadIdx.x];
-    atomicAdd(&acc[((int64_t)p * kNumCand + blockIdx.y) * 5 + threadIdx.x], t);
-  }
+  if (s_lo + (int)blockIdx.x >= s_hi) return;
+  unsigned long long v[5];
+  moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, s_lo + blockIdx.x, s_hi,
+                  gridDim.x, l_hi - l_lo, v);
+  reduce_moments(v, red, acc + ((int64_t)p * kNumCand + blockIdx.y) * 5);
 }
 
 // ---- exact 128-bit helpers -------------------------------------------------
@@ -688,37 +798,12 @@ __global__ void k_finalize(const PairDesc* desc, const int8_t* status_in, int n_
   if (best == -INFINITY) status[p] = MISTITCH_PAIR_NO_CANDIDATE;
 }
 
-__global__ void k_ncc_single(const uint16_t* a, int64_t pa, const uint16_t* b, int64_t pb, int h, int w,
-                             unsigned long long* acc) {
+__global__ __launch_bounds__(kThreads) void k_ncc_single(const uint16_t* a, int64_t pa, const uint16_t* b, int64_t pb,
+                                                         int h, int w, unsigned long long* acc) {
   __shared__ unsigned long long red[5 * kThreads / 64];
-  unsigned long long sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
-  for (int r = blockIdx.x; r < h; r += gridDim.x) {
-    for (int i = threadIdx.x; i < w; i += kThreads) {
-      const unsigned long long va = a[(int64_t)r * pa + i], vb = b[(int64_t)r * pb + i];
-      sa += va;
-      sb += vb;
-      saa += va * va;
-      sbb += vb * vb;
-      sab += va * vb;
-    }
-  }
-  unsigned long long v[5] = {sa, sb, saa, sbb, sab};
-#pragma unroll
-  for (int i = 0; i < 5; ++i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
-  }
-  const int wave = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i) red[wave * 5 + i] = v[i];
-  }
-  __syncthreads();
-  if (threadIdx.x < 5) {
-    unsigned long long t = 0;
-    for (int w2 = 0; w2 < kThreads / 64; ++w2) t += red[w2 * 5 + threadIdx.x];
-    atomicAdd(&acc[threadIdx.x], t);
-  }
+  unsigned long long v[5];
+  moments_of_rows(a, pa, b, pb, blockIdx.x, h, gridDim.x, w, v);
+  reduce_moments(v, red, acc);
 }
 
 __global__ void k_ncc_single_finish(const unsigned long long* acc, long long n, double* out) {
@@ -913,7 +998,7 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   }
   MS_REQUIRE(C >= 1, MISTITCH_ERR_UNSUPPORTED, "no column-pass decomposition for long side %d", L);
   cfg->C = C;
-  cfg->lds_cps = (size_t)S * 2 * C * esz;
+  cfg->lds_cps = ((size_t)S * 2 * C + (f64 ? Twiddles<double>::entries(S) : Twiddles<float>::entries(S))) * esz;
   MS_REQUIRE(cfg->lds_cps <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "short side %d needs %zu B of LDS", S, cfg->lds_cps);
   {
     const size_t ub = units.size() * sizeof(CpsUnit), sb = (size_t)L * sizeof(uint16_t);
@@ -935,8 +1020,9 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   while (nf & (nf - 1)) nf &= nf - 1;  // round down to a power of two
   cfg->NF_fwd = nf > S ? S : nf;
   cfg->NF_inv = nf > S / 2 ? S / 2 : nf;
-  cfg->lds_fwd = lb * cfg->NF_fwd;
-  cfg->lds_inv = lb * cfg->NF_inv;
+  const size_t twb = (size_t)(f64 ? Twiddles<double>::entries(L) : Twiddles<float>::entries(L)) * esz;
+  cfg->lds_fwd = lb * cfg->NF_fwd + twb;
+  cfg->lds_inv = lb * cfg->NF_inv + twb;
   MS_REQUIRE(cfg->lds_fwd <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "long side %d needs %zu B of LDS", L, cfg->lds_fwd);
   std::vector<char> blob(sizeof(ShapeCfg));
   memcpy(blob.data(), cfg, sizeof(ShapeCfg));
@@ -1076,8 +1162,12 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
                      pair_idx, pair_dir, status, 2e3);
   for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {
     const int n = std::min(chunk, n_pairs - pair0);
-    MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips, dim3((H + 31) / 32, (w_left + 31) / 32, 2 * n), dim3(32, 8), 0, tiles,
-                       tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
+    if (vec_top && H % 64 == 0 && w_left % 64 == 0)
+      MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips64, dim3(H / 64, w_left / 64, 2 * n), dim3(256), 0, tiles,
+                tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
+    else
+      MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips, dim3((H + 31) / 32, (w_left + 31) / 32, 2 * n), dim3(32, 8), 0,
+                tiles, tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
     if (same_shape) {
       // left strips come from the aligned staging buffer, top strips from the tiles
       rc = f64 ? launch_fft<double>(ctx, cfg_left, ws, status, pair0, n, -1, vec_top, k, nullptr)
