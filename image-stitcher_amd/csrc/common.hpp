@@ -131,6 +131,12 @@ struct Profiler {
 
 }  // namespace mistitch
 
+// Pins a loaded value in its register at this program point.  Placed after a
+// group of independent loads it keeps the compiler from sinking each load down to
+// its first use (which would serialise their latencies); the group is then issued
+// back to back and waited for once.
+#define MS_PIN(x) asm volatile("" : "+v"(x))
+
 // Launch on the context's stream, timed when profiling is enabled.
 #define MS_LAUNCH(ctx, name, kernel, grid, block, lds, ...)                     \
   do {                                                                          \
@@ -145,7 +151,7 @@ struct mistitch_ctx {
   hipStream_t stream = nullptr;
   int pair_chunk = 128;  // pairs processed per pipeline pass (bounds the FFT workspace)
   std::map<long long, mistitch::FftPlanHost> plans;  // key = n * 2 + (is_f64)
-  mistitch::DevBuf desc, staging, spectrum, partial, peaks, cand, acc, misc, bins;
+  mistitch::DevBuf desc, staging, spectrum, slabs, partial, peaks, cand, acc, misc, bins;
   std::vector<char> host_scratch;
   std::set<const void*> lds_enabled;  // kernels already granted large dynamic LDS
   std::map<long long, std::vector<char>> shapes;  // cached per-strip-shape launch configuration

@@ -29,8 +29,23 @@ constexpr int kBH = MS_FUSE_BH;             // block height in pixels
 constexpr int kMaxCand = 32;  // tiles remembered per block before the slow path
 
 struct __attribute__((packed, aligned(2))) Px8 {
-  uint16_t v[8];
+  unsigned d[4];  // 8 pixels, two per dword
+  __device__ __forceinline__ unsigned at(int i) const { return (d[i >> 1] >> (16 * (i & 1))) & 0xffffu; }
+  __device__ __forceinline__ void set(int i, unsigned px) {
+    d[i >> 1] = (i & 1) ? ((d[i >> 1] & 0xffffu) | (px << 16)) : ((d[i >> 1] & 0xffff0000u) | px);
+  }
 };
+#define MS_PIN_PX8(p) \
+  do {                \
+    MS_PIN((p).d[0]); \
+    MS_PIN((p).d[1]); \
+    MS_PIN((p).d[2]); \
+    MS_PIN((p).d[3]); \
+  } while (0)
+#define MS_PIN_8(p)                       \
+  do {                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) MS_PIN((p).v[i_]); \
+  } while (0)
 struct __attribute__((packed, aligned(4))) F8 {
   float v[8];
 };
@@ -69,7 +84,7 @@ __device__ __forceinline__ void fetch_window(const uint16_t* src, const void* ff
       const F8 f = *reinterpret_cast<const F8*>(ffrow);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float q = __fdiv_rn((float)v.v[i], f.v[i]);
+        float q = __fdiv_rn((float)v.at(i), f.v[i]);
         q = fminf(fmaxf(q, 0.0f), 65535.0f);
         px[i] = (uint16_t)(unsigned int)q;
       }
@@ -77,13 +92,13 @@ __device__ __forceinline__ void fetch_window(const uint16_t* src, const void* ff
       const D8 f = *reinterpret_cast<const D8*>(ffrow);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        double q = (double)v.v[i] / f.v[i];
+        double q = (double)v.at(i) / f.v[i];
         q = fmin(fmax(q, 0.0), 65535.0);
         px[i] = (uint16_t)(unsigned int)q;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) px[i] = v.v[i];
+      for (int i = 0; i < 8; ++i) px[i] = (uint16_t)v.at(i);
     }
   } else {
 #pragma unroll
@@ -288,7 +303,12 @@ __device__ __forceinline__ void slow_window(int y, int x, unsigned valid, const 
           sf64[q] = *reinterpret_cast<const D8*>(reinterpret_cast<const char*>(flatfields) +
                                                  ((int64_t)c.ff * H * W + in_tile) * (int64_t)ffsize);
       }
-      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        MS_PIN_PX8(sv[q]);
+        if constexpr (FF == MISTITCH_FF_F32) MS_PIN_8(sf32[q]);
+        if constexpr (FF == MISTITCH_FF_F64) MS_PIN_8(sf64[q]);
+      }
       float num[8], den[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) num[i] = den[i] = 0.0f;
@@ -300,15 +320,15 @@ __device__ __forceinline__ void slow_window(int y, int x, unsigned valid, const 
           for (int i = 0; i < 8; ++i) {
             float val;
             if constexpr (FF == MISTITCH_FF_F32) {
-              float t = __fdiv_rn((float)sv[q].v[i], sf32[q].v[i]);
+              float t = __fdiv_rn((float)sv[q].at(i), sf32[q].v[i]);
               t = fminf(fmaxf(t, 0.0f), 65535.0f);
               val = (float)(unsigned int)t;
             } else if constexpr (FF == MISTITCH_FF_F64) {
-              double t = (double)sv[q].v[i] / sf64[q].v[i];
+              double t = (double)sv[q].at(i) / sf64[q].v[i];
               t = fmin(fmax(t, 0.0), 65535.0);
               val = (float)(unsigned int)t;
             } else {
-              val = (float)sv[q].v[i];
+              val = (float)sv[q].at(i);
             }
             const int lx = lxs[q] + i;
             const float w = __fmul_rn(wy, (float)min(lx + 1, W - lx));
@@ -435,7 +455,12 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
       if constexpr (FF == MISTITCH_FF_F64)
         f64[r] = *reinterpret_cast<const D8*>(reinterpret_cast<const char*>(flatfields) + foff * (int64_t)ffsize);
     }
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < GX; ++r) {
+      MS_PIN_PX8(v[r]);
+      if constexpr (FF == MISTITCH_FF_F32) MS_PIN_8(f32[r]);
+      if constexpr (FF == MISTITCH_FF_F64) MS_PIN_8(f64[r]);
+    }
 #pragma unroll
     for (int r = 0; r < GX; ++r) {
       const unsigned k = (kinds >> (2 * r)) & 3u;
@@ -446,15 +471,15 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           if constexpr (FF == MISTITCH_FF_F32) {
-            float q = __fdiv_rn((float)v[r].v[i], f32[r].v[i]);
+            float q = __fdiv_rn((float)v[r].at(i), f32[r].v[i]);
             q = fminf(fmaxf(q, 0.0f), 65535.0f);
             px[i] = (uint16_t)(unsigned int)q;
           } else if constexpr (FF == MISTITCH_FF_F64) {
-            double q = (double)v[r].v[i] / f64[r].v[i];
+            double q = (double)v[r].at(i) / f64[r].v[i];
             q = fmin(fmax(q, 0.0), 65535.0);
             px[i] = (uint16_t)(unsigned int)q;
           } else {
-            px[i] = v[r].v[i];
+            px[i] = (uint16_t)v[r].at(i);
           }
         }
         store_window(rowp + x, px, 0xffu);
@@ -505,7 +530,7 @@ __global__ __launch_bounds__(256) void k_flatfield(const uint16_t* in, const voi
     fetch_window<FF>(src, ffrow, 0xffu, px);
     Px8 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o.v[i] = px[i];
+    for (int i = 0; i < 4; ++i) o.d[i] = px[2 * i] | ((unsigned)px[2 * i + 1] << 16);
     *reinterpret_cast<Px8*>(out + t * n_px_per_tile + q * 8) = o;
   }
 }
@@ -531,7 +556,7 @@ __global__ __launch_bounds__(256) void k_mip(const uint16_t* __restrict__ in, in
     for (int z = 1; z < n; ++z) {
       const Px8 v = *reinterpret_cast<const Px8*>(in + z * pitch + g * 8);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) best.v[i] = v.v[i] > best.v[i] ? v.v[i] : best.v[i];
+      for (int i = 0; i < 8; ++i) best.set(i, max(v.at(i), best.at(i)));
     }
     *reinterpret_cast<Px8*>(out + g * 8) = best;
   }

@@ -29,6 +29,19 @@
 
 namespace mistitch {
 
+#ifdef MS_STAMPS
+// Diagnostic build only: phase time stamps of the FFT kernels (never compiled into the shipped library).
+__device__ unsigned long long g_stamps[3][4096][8];
+#define MS_STAMP(kern, slot)                                                                    \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 4096) g_stamps[kern][blockIdx.x][slot] = wall_clock64(); \
+  } while (0)
+#else
+#define MS_STAMP(kern, slot) \
+  do {                       \
+  } while (0)
+#endif
+
 constexpr int kThreads = 256;
 constexpr int kMaxK = 16;       // peaks a block / a pair can report
 constexpr int kNumCand = 32;    // 2 peaks x 16 signed interpretations
@@ -63,6 +76,16 @@ template <typename T>
 __host__ __device__ __forceinline__ int spectrum_pitch(int L) {
   return L + 128 / (int)(2 * sizeof(T));
 }
+
+// Between the first long-axis pass and the column pass the spectrum is kept in
+// SLABS: the kSlab = 8 adjacent storage positions of every line are gathered into
+// one contiguous [S][8] piece (plus 128 bytes of padding), element (s, pos) at
+// (pos / 8) * slab_pitch + s * 8 + pos % 8.  The column pass then reads whole
+// slabs contiguously; the scattered accesses are all on the WRITING side, where
+// the memory system can batch them.
+constexpr int kSlab = 8;
+__host__ __device__ __forceinline__ int64_t slab_pitch(int S) { return (int64_t)S * kSlab + kSlab; }
+__host__ __device__ __forceinline__ int64_t slab_pair_elems(int S, int L) { return slab_pitch(S) * (L / kSlab); }
 
 __device__ __forceinline__ bool peak_better(double v, int k, double bv, int bk) {
   return (v > bv) || (v == bv && k > bk);
@@ -288,7 +311,7 @@ __global__ void k_transpose_plain(const uint16_t* src, int64_t pitch, int h, int
 template <typename T, bool VEC>
 __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc, const int8_t* status,
                                                            int pair0, int S, int L, int want_transposed,
-                                                           FftPlanDev planL, int NF, cx<T>* spectrum) {
+                                                           FftPlanDev planL, int NF, cx<T>* slabs) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
   const int p = pair0 + blockIdx.y;
@@ -297,6 +320,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
   if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
   const int tid = threadIdx.x;
   LineAddr<T> addr{LineAddr<T>::padded(L) + 1};
+  MS_STAMP(0, 0);
   const Twiddles<T> tw = load_twiddles<T>(buf + NF * addr.fstride, planL, tid, kThreads);
   const int s0 = blockIdx.x * NF;
   if constexpr (VEC) {
@@ -312,7 +336,11 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
         va[u] = *reinterpret_cast<const uint4*>(d.a + (int64_t)(s0 + f) * d.pitch + i);
         vb[u] = *reinterpret_cast<const uint4*>(d.b + (int64_t)(s0 + f) * d.pitch + i);
       }
-      __builtin_amdgcn_sched_barrier(0);  // keep every load ahead of the first LDS write
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        MS_PIN(va[u].x); MS_PIN(va[u].y); MS_PIN(va[u].z); MS_PIN(va[u].w);
+        MS_PIN(vb[u].x); MS_PIN(vb[u].y); MS_PIN(vb[u].z); MS_PIN(vb[u].w);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = e0 + u * kThreads * 8;
@@ -334,13 +362,17 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
     }
   }
   __syncthreads();
+  MS_STAMP(0, 1);
   fft_forward<T>(buf, addr, NF, planL, tw, tid, kThreads);
-  const int Lp = spectrum_pitch<T>(L);
-  cx<T>* out = spectrum + ((int64_t)blockIdx.y * S + s0) * Lp;
+  MS_STAMP(0, 2);
+  // element (s0 + f, pos) -> slab pos / 8; the NF lines of this block are adjacent in every slab
+  cx<T>* out = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L) + (int64_t)s0 * kSlab;
+  const int64_t sp = slab_pitch(S);
   for (int e = tid; e < NF * L; e += kThreads) {
-    const int f = e / L, i = e - f * L;
-    out[(int64_t)f * Lp + i] = buf[addr(f, i)];
+    const int c8 = e % kSlab, f = (e / kSlab) % NF, slab = e / (kSlab * NF);
+    out[slab * sp + f * kSlab + c8] = buf[addr(f, slab * kSlab + c8)];
   }
+  MS_STAMP(0, 3);
 }
 
 template <typename T>
@@ -368,7 +400,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
                                                             int pair0, int S, int L, int want_transposed,
                                                             FftPlanDev planS, FftPlanDev planL,
                                                             const CpsUnit* __restrict__ units, int rs,
-                                                            cx<T>* spectrum, T eps) {
+                                                            const cx<T>* __restrict__ slabs, cx<T>* spectrum, T eps) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
   const int p = pair0 + blockIdx.y;
@@ -382,9 +414,12 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   const int tid = threadIdx.x;
   const int Lp = spectrum_pitch<T>(L);
   cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
+  const cx<T>* Zs = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
+  const int64_t sp = slab_pitch(S);
+  MS_STAMP(1, 0);
   const Twiddles<T> tw = load_twiddles<T>(buf + S * rs, planS, tid, kThreads);
   {
-    constexpr int U = 8;  // loads in flight per lane before the first LDS write
+    constexpr int U = 16;  // loads in flight per lane before the first LDS write
     for (int e0 = tid; e0 < S * ncol; e0 += kThreads * U) {
       cx<T> r[U];
 #pragma unroll
@@ -392,9 +427,13 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
         const int e = min(e0 + u * kThreads, S * ncol - 1);  // clamp, do not branch around the load
         const int s = e / ncol, c = e - s * ncol;
         const int pos = c < na ? un.a0 + c : un.b0 + (c - na);
-        r[u] = Z[(int64_t)s * Lp + pos];
+        r[u] = Zs[(pos / kSlab) * sp + s * kSlab + pos % kSlab];
       }
-      __builtin_amdgcn_sched_barrier(0);  // keep every load ahead of the first LDS write
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        MS_PIN(r[u].x);
+        MS_PIN(r[u].y);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = e0 + u * kThreads;
@@ -407,7 +446,9 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   }
   __syncthreads();
   ColAddr<T> addr{rs};
+  MS_STAMP(1, 1);
   fft_forward<T>(buf, addr, ncol, planS, tw, tid, kThreads);
+  MS_STAMP(1, 2);
   for (int e = tid; e < S * na; e += kThreads) {
     const int q = e / na, c = e - q * na;
     const int mp = planL.mpos[un.a0 + c];
@@ -430,11 +471,14 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
     if (partner_in_a && (q2 * rs + pc) != (q * rs + c)) buf[q2 * rs + pc] = mk<T>(fx, -fy);
   }
   __syncthreads();
+  MS_STAMP(1, 3);
   fft_inverse<T>(buf, addr, na, planS, tw, tid, kThreads);
+  MS_STAMP(1, 4);
   for (int e = tid; e < S * na; e += kThreads) {
     const int s = e / na, c = e - s * na;
     Z[(int64_t)s * Lp + un.a0 + c] = buf[s * rs + c];
   }
+  MS_STAMP(1, 5);
 }
 
 // Inverse FFT along the long axis, two lines per complex transform, then the
@@ -442,7 +486,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc, const int8_t* status,
                                                            int pair0, int S, int L, int want_transposed,
-                                                           FftPlanDev planL, const uint16_t* __restrict__ srcpos,
+                                                           FftPlanDev planL, const uint16_t* __restrict__ stored_pos,
+                                                           const uint16_t* __restrict__ mirror_fill, int n_stored,
                                                            int NF, const cx<T>* spectrum, int k, Peak* partial,
                                                            int partial_stride, double* pcm_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -458,37 +503,42 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   const int s0 = blockIdx.x * NF * 2;
   const int Lp = spectrum_pitch<T>(L);
   const cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
+  MS_STAMP(2, 0);
   {
-    constexpr int U = 4;  // two loads per element: 8 in flight per lane
-    for (int e0 = tid; e0 < NF * L; e0 += kThreads * U) {
+    // Only the stored half of every line is read; the other half is its conjugate
+    // mirror and is written to LDS by the lane that loaded the stored value.
+    constexpr int U = 8;  // two loads per element: 16 in flight per lane
+    for (int e0 = tid; e0 < NF * n_stored; e0 += kThreads * U) {
       cx<T> g1[U], g2[U];
-      bool conj[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int e = min(e0 + u * kThreads, NF * L - 1);  // clamp, do not branch around the loads
-        const int f = e / L, pos = e - f * L;
-        const int src = srcpos[pos];  // where this frequency (or its conjugate partner) was stored
-        conj[u] = src != pos;
-        g1[u] = Z[(int64_t)(s0 + 2 * f) * Lp + src];
-        g2[u] = Z[(int64_t)(s0 + 2 * f + 1) * Lp + src];
+        const int e = min(e0 + u * kThreads, NF * n_stored - 1);  // clamp, do not branch around the loads
+        const int f = e / n_stored, i = e - f * n_stored;
+        const int pos = stored_pos[i];
+        g1[u] = Z[(int64_t)(s0 + 2 * f) * Lp + pos];
+        g2[u] = Z[(int64_t)(s0 + 2 * f + 1) * Lp + pos];
       }
-      __builtin_amdgcn_sched_barrier(0);  // keep every load ahead of the first LDS write
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        MS_PIN(g1[u].x); MS_PIN(g1[u].y);
+        MS_PIN(g2[u].x); MS_PIN(g2[u].y);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = e0 + u * kThreads;
-        if (e < NF * L) {
-          const int f = e / L, pos = e - f * L;
-          if (conj[u]) {
-            g1[u].y = -g1[u].y;
-            g2[u].y = -g2[u].y;
-          }
+        if (e < NF * n_stored) {
+          const int f = e / n_stored, i = e - f * n_stored;
+          const int pos = stored_pos[i], mir = mirror_fill[i];
           buf[addr(f, pos)] = mk<T>(g1[u].x - g2[u].y, g1[u].y + g2[u].x);  // g1 + i g2
+          if (mir != 0xffff) buf[addr(f, mir)] = mk<T>(g1[u].x + g2[u].y, g2[u].x - g1[u].y);  // conj(g1) + i conj(g2)
         }
       }
     }
   }
   __syncthreads();
+  MS_STAMP(2, 1);
   fft_inverse<T>(buf, addr, NF, planL, tw, tid, kThreads);
+  MS_STAMP(2, 2);
   const double scale = 1.0 / ((double)S * (double)L);
   if (pcm_out != nullptr) {
     double* out = pcm_out + (int64_t)blockIdx.y * S * L;
@@ -529,6 +579,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
     }
     __syncthreads();
   }
+  MS_STAMP(2, 3);
 }
 
 // Merge the per-block peaks of one pair and emit the candidate table.
@@ -905,7 +956,7 @@ static int build_plan(mistitch_ctx* ctx, int n, bool f64, FftPlanDev* out) {
 // negated frequencies, or merged into one self-contained range where negation
 // does not map block to block (the positions of the frequencies 0, M, 2M, ...).
 static bool build_units(const std::vector<uint16_t>& mpos, int L, int C, std::vector<CpsUnit>* units,
-                        std::vector<uint16_t>* srcpos) {
+                        std::vector<uint16_t>* stored_pos, std::vector<uint16_t>* mirror_fill) {
   const int nb = L / C;
   if (nb < 1) return false;
   std::vector<char> done(nb, 0);
@@ -938,13 +989,28 @@ static bool build_units(const std::vector<uint16_t>& mpos, int L, int C, std::ve
     }
     for (int g : group) done[g] = 1;
   }
-  srcpos->assign(L, 0);
+  // what the final long-axis pass reads: the stored positions, and for each the
+  // position (if any) that only exists as its conjugate mirror
   std::vector<char> stored(L, 0);
   for (const CpsUnit& u : *units)
     for (int i = 0; i < u.na; ++i) stored[u.a0 + i] = 1;
-  for (int pos = 0; pos < L; ++pos) (*srcpos)[pos] = stored[pos] ? (uint16_t)pos : mpos[pos];
+  stored_pos->clear();
+  mirror_fill->clear();
+  std::vector<char> covered(L, 0);
+  for (int pos = 0; pos < L; ++pos) {
+    if (!stored[pos]) continue;
+    stored_pos->push_back((uint16_t)pos);
+    covered[pos] = 1;
+    const int m = mpos[pos];
+    if (!stored[m]) {
+      mirror_fill->push_back((uint16_t)m);
+      covered[m] = 1;
+    } else {
+      mirror_fill->push_back(0xffff);
+    }
+  }
   for (int pos = 0; pos < L; ++pos)
-    if (!stored[(*srcpos)[pos]]) return false;
+    if (!covered[pos]) return false;
   return true;
 }
 
@@ -954,7 +1020,9 @@ struct ShapeCfg {
   int C;       // columns per block of the column pass (LDS rows hold 2C)
   const CpsUnit* units;    // device
   int n_units;
-  const uint16_t* srcpos;  // device: where k_fft_long_inv finds each frequency
+  const uint16_t* stored_pos;   // device: positions k_fft_short_cps wrote, ascending
+  const uint16_t* mirror_fill;  // device: per stored position, the position that is its conjugate (0xffff: none)
+  int n_stored;
   int NF_fwd;  // lines per k_fft_long_fwd block
   int NF_inv;  // line pairs per k_fft_long_inv block
   size_t lds_fwd, lds_cps, lds_inv;
@@ -989,27 +1057,31 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   MS_HIP(hipMemcpy(mpos.data(), cfg->planL.mpos, (size_t)L * 2, hipMemcpyDeviceToHost));
   // widest column block whose units exist and whose working set leaves room for two blocks per CU
   std::vector<CpsUnit> units;
-  std::vector<uint16_t> srcpos;
+  std::vector<uint16_t> stored_pos, mirror_fill;
   int C = 16;
   for (; C >= 1; C >>= 1) {
     if (C > L) continue;
     if (C > 1 && (size_t)S * 2 * C * esz > kLdsBudget) continue;
-    if (build_units(mpos, L, C, &units, &srcpos)) break;
+    if (build_units(mpos, L, C, &units, &stored_pos, &mirror_fill)) break;
   }
   MS_REQUIRE(C >= 1, MISTITCH_ERR_UNSUPPORTED, "no column-pass decomposition for long side %d", L);
   cfg->C = C;
   cfg->lds_cps = ((size_t)S * 2 * C + (f64 ? Twiddles<double>::entries(S) : Twiddles<float>::entries(S))) * esz;
   MS_REQUIRE(cfg->lds_cps <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "short side %d needs %zu B of LDS", S, cfg->lds_cps);
   {
-    const size_t ub = units.size() * sizeof(CpsUnit), sb = (size_t)L * sizeof(uint16_t);
+    const size_t ub = units.size() * sizeof(CpsUnit), sb = stored_pos.size() * sizeof(uint16_t);
     void* blob = nullptr;
-    MS_HIP(hipMalloc(&blob, ub + sb));
+    MS_HIP(hipMalloc(&blob, ub + 2 * sb));
     ctx->shape_allocs.push_back(blob);
-    MS_HIP(hipMemcpy(blob, units.data(), ub, hipMemcpyHostToDevice));
-    MS_HIP(hipMemcpy(reinterpret_cast<char*>(blob) + ub, srcpos.data(), sb, hipMemcpyHostToDevice));
-    cfg->units = reinterpret_cast<const CpsUnit*>(blob);
+    char* base = reinterpret_cast<char*>(blob);
+    MS_HIP(hipMemcpy(base, units.data(), ub, hipMemcpyHostToDevice));
+    MS_HIP(hipMemcpy(base + ub, stored_pos.data(), sb, hipMemcpyHostToDevice));
+    MS_HIP(hipMemcpy(base + ub + sb, mirror_fill.data(), sb, hipMemcpyHostToDevice));
+    cfg->units = reinterpret_cast<const CpsUnit*>(base);
     cfg->n_units = (int)units.size();
-    cfg->srcpos = reinterpret_cast<const uint16_t*>(reinterpret_cast<char*>(blob) + ub);
+    cfg->stored_pos = reinterpret_cast<const uint16_t*>(base + ub);
+    cfg->mirror_fill = reinterpret_cast<const uint16_t*>(base + ub + sb);
+    cfg->n_stored = (int)stored_pos.size();
   }
   const size_t lb = f64 ? line_bytes<double>(L) : line_bytes<float>(L);
   int nf = (int)(kLdsBudget / lb);
@@ -1043,7 +1115,8 @@ static int allow_lds(mistitch_ctx* ctx, KernelT kernel, size_t bytes) {
 struct RegWorkspace {
   PairDesc* desc;
   uint16_t* staging;
-  void* spectrum;
+  void* spectrum;  // [pairs][S][L + pad] rows: output of the column pass
+  void* slabs;     // [pairs][L / 8][S + 1][8]: output of the first long-axis pass
   Peak* partial;
   Peak* peaks;
   Cand* cand;
@@ -1052,11 +1125,13 @@ struct RegWorkspace {
 };
 
 static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, size_t staging_elems_per_pair,
-                                size_t spectrum_bytes_per_pair, int partial_stride, RegWorkspace* ws) {
+                                size_t spectrum_bytes_per_pair, size_t slab_bytes_per_pair, int partial_stride,
+                                RegWorkspace* ws) {
   int rc;
   if ((rc = ctx->desc.reserve((size_t)n_pairs * sizeof(PairDesc)))) return rc;
   if ((rc = ctx->staging.reserve((size_t)chunk * staging_elems_per_pair * 2 + 256))) return rc;
   if ((rc = ctx->spectrum.reserve((size_t)chunk * spectrum_bytes_per_pair))) return rc;
+  if ((rc = ctx->slabs.reserve((size_t)chunk * slab_bytes_per_pair))) return rc;
   if ((rc = ctx->partial.reserve((size_t)chunk * partial_stride * sizeof(Peak)))) return rc;
   if ((rc = ctx->peaks.reserve((size_t)n_pairs * kMaxK * sizeof(Peak)))) return rc;
   if ((rc = ctx->cand.reserve((size_t)n_pairs * kNumCand * sizeof(Cand)))) return rc;
@@ -1064,6 +1139,7 @@ static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, size_
   ws->desc = (PairDesc*)ctx->desc.ptr;
   ws->staging = (uint16_t*)ctx->staging.ptr;
   ws->spectrum = ctx->spectrum.ptr;
+  ws->slabs = ctx->slabs.ptr;
   ws->partial = (Peak*)ctx->partial.ptr;
   ws->peaks = (Peak*)ctx->peaks.ptr;
   ws->cand = (Cand*)ctx->cand.ptr;
@@ -1077,23 +1153,25 @@ template <typename T>
 static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace& ws, const int8_t* status,
                       int pair0, int n, int want_transposed, bool vec_ok, int k, double* pcm_out) {
   cx<T>* spec = reinterpret_cast<cx<T>*>(ws.spectrum);
+  cx<T>* slabs = reinterpret_cast<cx<T>*>(ws.slabs);
   int rc;
   if (vec_ok) {
     if ((rc = allow_lds(ctx, k_fft_long_fwd<T, true>, cfg.lds_fwd))) return rc;
     MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd<T, true>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd,
-                       ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, spec);
+                       ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, slabs);
   } else {
     if ((rc = allow_lds(ctx, k_fft_long_fwd<T, false>, cfg.lds_fwd))) return rc;
     MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd<T, false>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd,
-                       ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, spec);
+                       ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, slabs);
   }
   if ((rc = allow_lds(ctx, k_fft_short_cps<T>, cfg.lds_cps))) return rc;
   const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
   MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<T>), dim3(cfg.n_units, n), dim3(kThreads), cfg.lds_cps, ws.desc, status,
-            pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, spec, eps);
+            pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps);
   if ((rc = allow_lds(ctx, k_fft_long_inv<T>, cfg.lds_inv))) return rc;
   MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv<T>), dim3(cfg.S / (2 * cfg.NF_inv), n), dim3(kThreads), cfg.lds_inv, ws.desc,
-                     status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.srcpos, cfg.NF_inv, spec, k, ws.partial,
+                     status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored,
+            cfg.NF_inv, spec, k, ws.partial,
                      ws.partial_stride, pcm_out);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
@@ -1104,6 +1182,12 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 }  // namespace mistitch
 
 using namespace mistitch;
+
+#ifdef MS_STAMPS
+extern "C" int mistitch_debug_stamps(unsigned long long* host_out /*[3][4096][8]*/) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 3 * 4096 * 8) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int edge_width,
                                              int max_pairs, unsigned flags) {
@@ -1122,7 +1206,8 @@ extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int 
   const int pstride = std::max(a.S / (2 * a.NF_inv), b.S / (2 * b.NF_inv)) * kMaxK;
   const int chunk = max_pairs < ctx->pair_chunk ? max_pairs : ctx->pair_chunk;
   RegWorkspace ws;
-  return reserve_registration(ctx, max_pairs, chunk, (size_t)w_left * tile_h * 2, spec, pstride, &ws);
+  const size_t slab = (size_t)std::max(slab_pair_elems(a.S, a.L), slab_pair_elems(b.S, b.L)) * esz;
+  return reserve_registration(ctx, max_pairs, chunk, (size_t)w_left * tile_h * 2, spec, slab, pstride, &ws);
 }
 
 extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h,
@@ -1151,7 +1236,9 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
   const int pstride = std::max(cfg_left.S / (2 * cfg_left.NF_inv), cfg_top.S / (2 * cfg_top.NF_inv)) * kMaxK;
   const int chunk = n_pairs < ctx->pair_chunk ? n_pairs : ctx->pair_chunk;
   RegWorkspace ws;
-  if ((rc = reserve_registration(ctx, n_pairs, chunk, (size_t)w_left * H * 2, spec, pstride, &ws))) return rc;
+  const size_t slab =
+      (size_t)std::max(slab_pair_elems(cfg_left.S, cfg_left.L), slab_pair_elems(cfg_top.S, cfg_top.L)) * esz;
+  if ((rc = reserve_registration(ctx, n_pairs, chunk, (size_t)w_left * H * 2, spec, slab, pstride, &ws))) return rc;
   // 16-byte loads of tile rows need aligned rows; staging lines always are.
   const bool vec_top = aligned16(tiles) && (W % 8 == 0) && (tile_pitch % 8 == 0);
   const int k = 2;  // peaks the candidate search consumes
@@ -1211,7 +1298,9 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   const size_t esz = f64 ? 16 : 8;
   const int pstride = (cfg.S / (2 * cfg.NF_inv)) * kMaxK;
   RegWorkspace ws;
-  if ((rc = reserve_registration(ctx, 1, 1, (size_t)S * L, (size_t)S * (L + 128 / esz) * esz, pstride, &ws))) return rc;
+  if ((rc = reserve_registration(ctx, 1, 1, (size_t)S * L, (size_t)S * (L + 128 / esz) * esz,
+                                 (size_t)slab_pair_elems(S, L) * esz, pstride, &ws)))
+    return rc;
   if ((rc = ctx->misc.reserve(256))) return rc;
   hipStream_t st = ctx->stream;
   PairDesc d;
