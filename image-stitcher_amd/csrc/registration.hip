@@ -556,9 +556,45 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
     }
   }
   if (k <= 0) return;
-  // k rounds of block argmax; a taken element is overwritten with -inf.
   T* flat = reinterpret_cast<T*>(buf);
   const T neg_inf = -std::numeric_limits<T>::infinity();
+  if (k <= 2) {
+    // The production case: one scan keeps each lane's two best values, then k argmax
+    // rounds in which a lane whose best was taken offers its second best.
+    Peak b1{-INFINITY, -1, -1}, b2{-INFINITY, -1, -1};
+    for (int e = tid; e < NF * L; e += kThreads) {
+      const int f = e / L, l = e - f * L;
+      const int a0 = addr(f, l);
+      const cx<T> v = buf[a0];
+      const int s = s0 + 2 * f;
+      const int key0 = d.transposed ? l * S + s : s * L + l;
+      const int key1 = d.transposed ? key0 + 1 : key0 + L;
+      const Peak c0{(double)v.x * scale, key0, 2 * a0}, c1{(double)v.y * scale, key1, 2 * a0 + 1};
+      if (peak_better(c0.val, c0.key, b1.val, b1.key)) {
+        b2 = b1;
+        b1 = c0;
+      } else if (peak_better(c0.val, c0.key, b2.val, b2.key)) {
+        b2 = c0;
+      }
+      if (peak_better(c1.val, c1.key, b1.val, b1.key)) {
+        b2 = b1;
+        b1 = c1;
+      } else if (peak_better(c1.val, c1.key, b2.val, b2.key)) {
+        b2 = c1;
+      }
+    }
+    for (int round = 0; round < k; ++round) {
+      const Peak best = block_argmax(b1, red);
+      if (tid == 0) partial[(int64_t)blockIdx.y * partial_stride + blockIdx.x * k + round] = best;
+      if (best.loc >= 0 && best.loc == b1.loc) {
+        b1 = b2;
+        b2 = Peak{-INFINITY, -1, -1};
+      }
+    }
+    MS_STAMP(2, 3);
+    return;
+  }
+  // k rounds of block argmax; a taken element is overwritten with -inf.
   for (int round = 0; round < k; ++round) {
     Peak mine{-INFINITY, -1, -1};
     for (int e = tid; e < NF * L; e += kThreads) {
