@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--pair-chunk", type=int, default=None)
     ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side figures (other fusion mode, other FFT precision): profiler runs")
     return ap.parse_args()
 
 
@@ -91,6 +93,21 @@ def build_device_acquisition(cfg, seed, device):
         del scene
     pair_idx, pair_dir = synth.grid_pairs(rows, cols)
     return tiles.view(torch.uint16), true_yx, pair_idx, pair_dir
+
+
+def load_pmc_traffic(workload, fft):
+    """HBM bytes per launch of each kernel, from the committed rocprofv3 --pmc passes
+    (2 x FETCH_SIZE + WRITE_SIZE, see tools/pmc_summary.py); {} when none is recorded.
+    Counters cannot be collected from inside this process, so they are measured by
+    separate profiler runs of this same command and read back here."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as fh:
+        doc = json.load(fh)
+    if doc.get("workload") != workload or doc.get("fft") != fft:
+        return {}
+    return {k: v["hbm_bytes_per_launch"] for k, v in doc.get("kernels", {}).items()}
 
 
 def cpu_baseline(n_pairs_target, edge_width, tile, fuse_mode, with_ff):
@@ -147,7 +164,11 @@ def main():
     tile, ch = cfg["tile"], cfg["channels"]
     edge = args.edge_width or (256 if tile >= 2048 else tile // 8)
     fft_flag = _lib.FFT_F64 if args.fft == "f64" else _lib.FFT_F32
+    other_fft = "f32" if args.fft == "f64" else "f64"
+    other_fft_flag = _lib.FFT_F32 if args.fft == "f64" else _lib.FFT_F64
     mode_id = _lib.FUSE_FEATHER if args.fuse_mode == "feather" else _lib.FUSE_OVERWRITE
+    other_mode = "overwrite" if args.fuse_mode == "feather" else "feather"
+    other_mode_id = _lib.FUSE_OVERWRITE if args.fuse_mode == "feather" else _lib.FUSE_FEATHER
 
     ctx = _lib.Context(local_rank, torch.cuda.current_stream(device).cuda_stream, pair_chunk=args.pair_chunk)
     tiles, true_yx, pair_idx, pair_dir = build_device_acquisition(cfg, seed=3 + rank, device=device)
@@ -162,6 +183,7 @@ def main():
     d_pair_dir = torch.as_tensor(pair_dir, dtype=torch.uint8, device=device)
     d_out = torch.empty((n_pairs, 3), dtype=torch.float64, device=device)
     d_status = torch.empty((n_pairs,), dtype=torch.int8, device=device)
+    d_out2, d_status2 = torch.empty_like(d_out), torch.empty_like(d_status)
     d_yx = torch.as_tensor(np.tile(yx_np, (ch, 1)), dtype=torch.int32, device=device)
     d_plane = torch.as_tensor(np.repeat(np.arange(ch), n_tiles), dtype=torch.int32, device=device)
     mosaic = torch.empty((ch, mosaic_h, mosaic_w), dtype=torch.int16, device=device).view(torch.uint16)
@@ -186,10 +208,25 @@ def main():
         if world > 1:
             gathered = mdist.all_gather_pair_results(d_out, d_status, counts)
 
-    def step_fusion():
+    def step_registration_other():
+        """The same step at the other FFT precision (reported beside the headline figure)."""
+        if ffs is not None:
+            check(lib.mistitch_apply_flatfield(ctx.handle, ptr(tiles[0]), ptr(ffs[0]), ff_type, ptr(reg_tiles),
+                                               n_tiles, tile, tile))
+        check(lib.mistitch_register_pairs(ctx.handle, ptr(reg_tiles), n_tiles, tile, tile, tile * tile,
+                                          ptr(d_pair_idx), ptr(d_pair_dir), n_pairs, edge, other_fft_flag,
+                                          ptr(d_out2), ptr(d_status2)))
+
+    def fuse(mode):
         check(lib.mistitch_fuse(ctx.handle, ptr(tiles), ch * n_tiles, tile, tile, tile * tile, ptr(d_yx), ptr(d_plane),
                                 ptr(ffs), ff_type, ptr(d_plane) if ffs is not None else ptr(None), ptr(mosaic), ch,
-                                mosaic_h, mosaic_w, 0, mosaic_h, mode_id))
+                                mosaic_h, mosaic_w, 0, mosaic_h, mode))
+
+    def step_fusion():
+        fuse(mode_id)
+
+    def step_fusion_other():
+        fuse(other_mode_id)
 
     def bracket():
         if world > 1:
@@ -214,6 +251,14 @@ def main():
         step_fusion()
     t_reg = timed(step_registration, args.steps)
     t_fuse = timed(step_fusion, args.steps)
+    # side figures: the other fusion mode and the other FFT precision, same bracketing
+    side = not args.no_side
+    if side:
+        step_fusion_other()
+        t_fuse_other = timed(step_fusion_other, args.steps)
+        step_registration_other()
+        t_reg_other = timed(step_registration_other, args.steps)
+        out2_np, st2_np = d_out2.cpu().numpy(), d_status2.cpu().numpy()
 
     # ---- parity properties at full size: every planted shift recovered, mosaic spot checks ----
     out_np, st_np = d_out.cpu().numpy(), d_status.cpu().numpy()
@@ -228,6 +273,8 @@ def main():
         for _ in range(psteps):
             step_registration()
             step_fusion()
+            if side:
+                step_fusion_other()
         for name, (ms, launches) in ctx.profile_collect().items():
             kernels[name] = dict(ms_per_step=ms / psteps, launches_per_step=launches / psteps,
                                  avg_launch_us=1e3 * ms / launches)
@@ -239,10 +286,12 @@ def main():
     cplx = 16 if args.fft == "f64" else 8
     covered = union_area(yx_np, tile, tile)
     clipped_tile_px = n_tiles * tile * tile                    # every tile lies inside the mosaic here
-    fuse_bytes = ch * ((2 * clipped_tile_px + 2 * mosaic_h * mosaic_w) if args.fuse_mode == "feather"
-                       else (4 * covered + 2 * (mosaic_h * mosaic_w - covered)))
+    fuse_bytes_by_mode = {"feather": ch * (2 * clipped_tile_px + 2 * mosaic_h * mosaic_w),
+                          "overwrite": ch * (4 * covered + 2 * (mosaic_h * mosaic_w - covered))}
     if ffs is not None:
-        fuse_bytes += ch * tile * tile * 4                     # flatfield planes, read once (cache resident)
+        for m in fuse_bytes_by_mode:
+            fuse_bytes_by_mode[m] += ch * tile * tile * 4      # flatfield planes, read once (cache resident)
+    fuse_bytes = fuse_bytes_by_mode[args.fuse_mode]
     alg_bytes_per_step = {
         "k_fft_long_fwd": n_pairs * (2 * strip_px * 2 + strip_px * cplx),
         "k_fft_short_cps": n_pairs * (strip_px * cplx + (strip_px // 2) * cplx),
@@ -250,22 +299,30 @@ def main():
         "k_ncc_accumulate": n_pairs * 2 * strip_px * 2,
         "k_transpose_strips": int((pair_dir == 0).sum()) * 2 * strip_px * 2 * 2,
         "k_flatfield": n_tiles * tile * tile * 4 + tile * tile * 4,
-        "k_fuse_feather": fuse_bytes, "k_fuse_overwrite": fuse_bytes,
+        "k_fuse_feather": fuse_bytes_by_mode["feather"], "k_fuse_overwrite": fuse_bytes_by_mode["overwrite"],
     }
+    traffic = load_pmc_traffic(args.workload, args.fft)
     rooflines = {}
     for name, k in kernels.items():
         if name in alg_bytes_per_step and k["ms_per_step"] > 0:
             gbs = alg_bytes_per_step[name] / (k["ms_per_step"] * 1e-3) / 1e9
             rooflines[name] = dict(bound="hbm", achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                                   frac=round(gbs / HBM_PEAK_GBS, 4), traffic=None,
+                                   frac=round(gbs / HBM_PEAK_GBS, 4), traffic=traffic.get(name),
                                    avg_launch_us=round(k["avg_launch_us"], 2),
                                    algorithmic_bytes_per_launch=int(alg_bytes_per_step[name] / k["launches_per_step"]))
-    dominant = max(rooflines, key=lambda n: kernels[n]["ms_per_step"]) if rooflines else None
+    # the dominant kernel of the configured step (the other fusion mode is a side figure)
+    in_step = [n for n in rooflines if n != f"k_fuse_{other_mode}"]
+    dominant = max(in_step, key=lambda n: kernels[n]["ms_per_step"]) if in_step else None
 
     pairs_per_s = world * n_pairs * args.steps / t_reg
     mpix_per_step = ch * mosaic_h * mosaic_w / 1e6
     mpix_per_s = world * mpix_per_step * args.steps / t_fuse
     fuse_gbs = fuse_bytes * args.steps / t_fuse / 1e9            # per GPU
+    if side:
+        mpix_per_s_other = world * mpix_per_step * args.steps / t_fuse_other
+        fuse_gbs_other = fuse_bytes_by_mode[other_mode] * args.steps / t_fuse_other / 1e9
+        pairs_per_s_other = world * n_pairs * args.steps / t_reg_other
+        shifts_ok_other = bool((st2_np == 0).all() and np.array_equal(out2_np[:, 1:].astype(np.int64), expected))
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_pairs > 0:
@@ -299,13 +356,26 @@ def main():
             "fusion": {"metric": "fused_mosaic_MPix_per_sec", "value": round(mpix_per_s, 1), "unit": "MPix/s",
                        "dtype": "u16", "mode": args.fuse_mode, "ms_per_step": round(1e3 * t_fuse / args.steps, 3),
                        "roofline": {"bound": "hbm", "achieved": round(fuse_gbs, 1), "peak": HBM_PEAK_GBS,
-                                    "unit": "GB/s", "frac": round(fuse_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                                    "unit": "GB/s", "frac": round(fuse_gbs / HBM_PEAK_GBS, 4),
+                                    "traffic": traffic.get(f"k_fuse_{args.fuse_mode}"),
                                     "algorithmic_bytes_per_launch": int(fuse_bytes)}},
             "parity": {"planted_integer_shifts_recovered": shifts_ok, "pairs_checked": int(n_pairs)},
             "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
             "kernels": {n: {**{k: round(v, 3) for k, v in kernels[n].items()},
                             **({"hbm_frac": rooflines[n]["frac"]} if n in rooflines else {})} for n in kernels},
         }
+        if side:
+            line["fusion_" + other_mode] = {
+                "value": round(mpix_per_s_other, 1), "unit": "MPix/s",
+                "ms_per_step": round(1e3 * t_fuse_other / args.steps, 3),
+                "roofline": {"bound": "hbm", "achieved": round(fuse_gbs_other, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(fuse_gbs_other / HBM_PEAK_GBS, 4),
+                             "traffic": traffic.get(f"k_fuse_{other_mode}"),
+                             "algorithmic_bytes_per_launch": int(fuse_bytes_by_mode[other_mode])}}
+            line["registration_" + other_fft] = {
+                "value": round(pairs_per_s_other, 1), "unit": "tile-pairs/s",
+                "ms_per_step": round(1e3 * t_reg_other / args.steps, 3),
+                "planted_integer_shifts_recovered": shifts_ok_other}
         if cpu is not None:
             cpu_pairs_s = cpu["pairs"] / cpu["t_reg"]
             line["cpu_baseline"] = {
