@@ -151,7 +151,7 @@ struct mistitch_ctx {
   hipStream_t stream = nullptr;
   int pair_chunk = 128;  // pairs processed per pipeline pass (bounds the FFT workspace)
   std::map<long long, mistitch::FftPlanHost> plans;  // key = n * 2 + (is_f64)
-  mistitch::DevBuf desc, staging, spectrum, slabs, partial, peaks, cand, acc, misc, bins;
+  mistitch::DevBuf desc, staging, spectrum, slabs, partial, peaks, cand, acc, misc, bins, flags;
   std::vector<char> host_scratch;
   std::set<const void*> lds_enabled;  // kernels already granted large dynamic LDS
   std::map<long long, std::vector<char>> shapes;  // cached per-strip-shape launch configuration

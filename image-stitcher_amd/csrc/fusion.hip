@@ -27,6 +27,11 @@ constexpr int kGxPlain = MS_FUSE_GX_PLAIN;  // groups per lane and row without f
 constexpr int kGxFlat = MS_FUSE_GX_FF;      // with flatfield: fewer, the flatfield values take registers too
 constexpr int kBH = MS_FUSE_BH;             // block height in pixels
 constexpr int kMaxCand = 32;  // tiles remembered per block before the slow path
+static_assert(kBH <= 32 && kMaxCand == 32, "queue entries hold 5-bit rows and candidate indices");
+
+#ifndef MS_FDIV
+#define MS_FDIV(a, b) __fdiv_rn((a), (b))
+#endif
 
 struct __attribute__((packed, aligned(2))) Px8 {
   unsigned d[4];  // 8 pixels, two per dword
@@ -54,15 +59,30 @@ struct __attribute__((packed, aligned(8))) D8 {
 };
 
 struct TileRef {
-  int ty, tx;  // mosaic position of the tile origin
-  int t;       // tile index
-  int ff;      // flatfield plane or -1
+  int ty, tx;        // mosaic position of the tile origin
+  int t;             // tile index
+  int ff;            // flatfield plane or -1
+  int64_t src_base;  // element offset, in the tile array, of the tile pixel under mosaic pixel (y, x) is src_base + y * W + x
+  int64_t ff_base;   // the same in the flatfield array (0 without a plane)
 };
+
+__device__ __forceinline__ TileRef make_ref(int t, const int32_t* __restrict__ tile_yx, const int32_t* tile_ff, int H,
+                                            int W, int64_t tile_pitch) {
+  TileRef c;
+  c.ty = tile_yx[2 * t];
+  c.tx = tile_yx[2 * t + 1];
+  c.t = t;
+  c.ff = tile_ff ? tile_ff[t] : -1;
+  const int64_t origin = (int64_t)c.ty * W + c.tx;
+  c.src_base = (int64_t)t * tile_pitch - origin;
+  c.ff_base = c.ff >= 0 ? (int64_t)c.ff * H * W - origin : 0;
+  return c;
+}
 
 template <int FF>
 __device__ __forceinline__ uint16_t flatfield_one(uint16_t v, const void* ffrow, int i) {
   if constexpr (FF == MISTITCH_FF_F32) {
-    float q = __fdiv_rn((float)v, reinterpret_cast<const float*>(ffrow)[i]);
+    float q = MS_FDIV((float)v, reinterpret_cast<const float*>(ffrow)[i]);
     q = fminf(fmaxf(q, 0.0f), 65535.0f);
     return (uint16_t)(unsigned int)q;
   } else if constexpr (FF == MISTITCH_FF_F64) {
@@ -84,7 +104,7 @@ __device__ __forceinline__ void fetch_window(const uint16_t* src, const void* ff
       const F8 f = *reinterpret_cast<const F8*>(ffrow);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        float q = __fdiv_rn((float)v.at(i), f.v[i]);
+        float q = MS_FDIV((float)v.at(i), f.v[i]);
         q = fminf(fmaxf(q, 0.0f), 65535.0f);
         px[i] = (uint16_t)(unsigned int)q;
       }
@@ -122,8 +142,10 @@ __device__ __forceinline__ void fetch_window(const uint16_t* src, const void* ff
 // grid = ceil(n_blocks / 4) workgroups of 4 waves; blocks are numbered as k_fuse's grid.
 __global__ __launch_bounds__(256) void k_fuse_bins(int n_tiles, int H, int W, const int32_t* __restrict__ tile_yx,
                                                    const int32_t* __restrict__ tile_plane, int32_t* __restrict__ bins,
-                                                   int gx, int gy, int n_planes, int Wm, int row0, int row1, int kBW) {
+                                                   int gx, int gy, int n_planes, int Wm, int row0, int row1, int kBW,
+                                                   int32_t* ff_verdict) {
   const int lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *ff_verdict = 1;  // k_ff_check, next on the stream, may clear it
   const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blk >= (int64_t)gx * gy * n_planes) return;
   const int bx = (int)(blk % gx), by = (int)((blk / gx) % gy), plane = (int)(blk / ((int64_t)gx * gy));
@@ -182,7 +204,7 @@ __device__ __forceinline__ void resolve_window(int y, int x, unsigned valid, con
         c = list[ci];
       } else {
         if (tile_plane[ci] != plane) continue;
-        c = TileRef{tile_yx[2 * ci], tile_yx[2 * ci + 1], ci, tile_ff ? tile_ff[ci] : -1};
+        c = make_ref(ci, tile_yx, tile_ff, H, W, tile_pitch);
       }
       const int ly = y - c.ty;
       if ((unsigned)ly >= (unsigned)H) continue;
@@ -214,7 +236,7 @@ __device__ __forceinline__ void resolve_window(int y, int x, unsigned valid, con
         c = list[ci];
       } else {
         if (tile_plane[ci] != plane) continue;
-        c = TileRef{tile_yx[2 * ci], tile_yx[2 * ci + 1], ci, tile_ff ? tile_ff[ci] : -1};
+        c = make_ref(ci, tile_yx, tile_ff, H, W, tile_pitch);
       }
       const int ly = y - c.ty;
       if ((unsigned)ly >= (unsigned)H) continue;
@@ -249,7 +271,7 @@ __device__ __forceinline__ void resolve_window(int y, int x, unsigned valid, con
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         if (den[i] > 0.0f) {
-          const float q = floorf(__fadd_rn(__fdiv_rn(num[i], den[i]), 0.5f));
+          const float q = floorf(__fadd_rn(MS_FDIV(num[i], den[i]), 0.5f));
           px[i] = (uint16_t)(unsigned int)fminf(q, 65535.0f);
         }
       }
@@ -257,116 +279,182 @@ __device__ __forceinline__ void resolve_window(int y, int x, unsigned valid, con
   }
 }
 
-// A group whose pixels come from several tiles, or only partly from one.  Feather
-// groups that two to four tiles cover completely (the inside of an overlap band)
-// are blended from loads issued together; everything else goes pixel by pixel.
-template <int MODE, int FF>
-__device__ __forceinline__ void slow_window(int y, int x, unsigned valid, const TileRef* list, int ncand, bool overflow,
-                                            int plane, const uint16_t* __restrict__ tiles, int H, int W,
-                                            int64_t tile_pitch, const int32_t* __restrict__ tile_yx,
-                                            const int32_t* __restrict__ tile_plane,
-                                            const void* __restrict__ flatfields,
-                                            const int32_t* __restrict__ tile_ff, uint16_t (&px)[8]) {
-  constexpr size_t ffsize = FF == MISTITCH_FF_F64 ? 8 : 4;
-  if constexpr (MODE == MISTITCH_FUSE_FEATHER) {
-    int touching = 0;
-    bool all_full = valid == 0xffu && !overflow;
-    unsigned packed = 0;  // up to four candidate indices, one per byte, in placement order
-    if (all_full) {
-      for (int ci = 0; ci < ncand; ++ci) {
-        const TileRef c = list[ci];
-        const int ly = y - c.ty, lx0 = x - c.tx;
-        if ((unsigned)ly >= (unsigned)H) continue;
-        const int lo = max(0, -lx0), hi = min(8, W - lx0);
-        if (lo >= hi) continue;
-        if (touching < 4) packed |= (unsigned)ci << (8 * touching);
-        ++touching;
-        all_full = all_full && lo == 0 && hi == 8 && (FF == MISTITCH_FF_NONE || c.ff >= 0);
-      }
-    }
-    if (all_full && touching >= 2 && touching <= 4) {
-      Px8 sv[4];
-      F8 sf32[FF == MISTITCH_FF_F32 ? 4 : 1];
-      D8 sf64[FF == MISTITCH_FF_F64 ? 4 : 1];
-      int lys[4], lxs[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const TileRef c = list[(packed >> (8 * (q < touching ? q : 0))) & 0xffu];
-        lys[q] = y - c.ty;
-        lxs[q] = x - c.tx;
-        const int64_t in_tile = (int64_t)lys[q] * W + lxs[q];
-        sv[q] = *reinterpret_cast<const Px8*>(tiles + (int64_t)c.t * tile_pitch + in_tile);
-        if constexpr (FF == MISTITCH_FF_F32)
-          sf32[q] = *reinterpret_cast<const F8*>(reinterpret_cast<const char*>(flatfields) +
-                                                 ((int64_t)c.ff * H * W + in_tile) * (int64_t)ffsize);
-        if constexpr (FF == MISTITCH_FF_F64)
-          sf64[q] = *reinterpret_cast<const D8*>(reinterpret_cast<const char*>(flatfields) +
-                                                 ((int64_t)c.ff * H * W + in_tile) * (int64_t)ffsize);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        MS_PIN_PX8(sv[q]);
-        if constexpr (FF == MISTITCH_FF_F32) MS_PIN_8(sf32[q]);
-        if constexpr (FF == MISTITCH_FF_F64) MS_PIN_8(sf64[q]);
-      }
-      float num[8], den[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) num[i] = den[i] = 0.0f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (q < touching) {
-          const float wy = (float)min(lys[q] + 1, H - lys[q]);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            float val;
-            if constexpr (FF == MISTITCH_FF_F32) {
-              float t = __fdiv_rn((float)sv[q].at(i), sf32[q].v[i]);
-              t = fminf(fmaxf(t, 0.0f), 65535.0f);
-              val = (float)(unsigned int)t;
-            } else if constexpr (FF == MISTITCH_FF_F64) {
-              double t = (double)sv[q].at(i) / sf64[q].v[i];
-              t = fmin(fmax(t, 0.0), 65535.0);
-              val = (float)(unsigned int)t;
-            } else {
-              val = (float)sv[q].at(i);
-            }
-            const int lx = lxs[q] + i;
-            const float w = __fmul_rn(wy, (float)min(lx + 1, W - lx));
-            num[i] = __fadd_rn(num[i], __fmul_rn(w, val));
-            den[i] = __fadd_rn(den[i], w);
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const float t = floorf(__fadd_rn(__fdiv_rn(num[i], den[i]), 0.5f));
-        px[i] = (uint16_t)(unsigned int)fminf(t, 65535.0f);
-      }
-      return;
-    }
-  }
-  resolve_window<MODE, FF>(y, x, valid, list, ncand, overflow, plane, tiles, H, W, tile_pitch, tile_yx, tile_plane,
-                           flatfields, tile_ff, px);
+// ---- two pixels per instruction -------------------------------------------------
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// n / d, correctly rounded, for operands that need no range scaling (d a normal
+// number of moderate exponent, the quotient neither overflowing nor denormal).
+// It is the fma chain of the IEEE-exact division expansion (v_div_scale ...
+// v_div_fixup) with the scaling steps, which are the identity for such operands,
+// left out, on two quotients at once (v_pk_fma_f32).
+__device__ __forceinline__ f2 div2_noscale(f2 n, f2 d) {
+  f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const f2 one = {1.0f, 1.0f};
+  const f2 e = pk_fma(-d, r, one);
+  r = pk_fma(e, r, r);
+  f2 q = n * r;
+  f2 t = pk_fma(-d, q, n);
+  q = pk_fma(t, r, q);
+  t = pk_fma(-d, q, n);
+  return pk_fma(t, r, q);
 }
 
-// 1-D grid of 8 * gx * ceil(gy * n_planes / 8) workgroups with
+// n / d for an integer numerator 0..65535 and a denominator within [2^-16, 2^16]:
+// one Newton step on the hardware reciprocal and one residual correction give the
+// correctly rounded quotient for every such pair (checked exhaustively on gfx950 over
+// all 2^16 numerators x 2^23 denominator mantissas by tools/div_check.hip; powers of
+// two scale every intermediate exactly).
+__device__ __forceinline__ f2 div2_u16(f2 n, f2 d) {
+  f2 r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+  const f2 one = {1.0f, 1.0f};
+  const f2 e = pk_fma(-d, r, one);
+  r = pk_fma(e, r, r);
+  const f2 q = n * r;
+  const f2 t = pk_fma(-d, q, n);
+  return pk_fma(t, r, q);
+}
+
+// Flatfield-corrected values of 8 pixels, trunc(clip(v / ff)), as unsigned integers in
+// [0, 65535].  SAFE: every flatfield value is known to be finite and within
+// [2^-16, 2^16] (checked once per call by k_ff_check), which admits div2_u16.
+template <int FF, bool SAFE>
+__device__ __forceinline__ void corrected8(const Px8& v, const F8& f32, const D8& f64, unsigned (&out)[8]) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const unsigned d = v.d[p];
+    if constexpr (FF == MISTITCH_FF_F32) {
+      const f2 n = {(float)(d & 0xffffu), (float)(d >> 16)};
+      if constexpr (SAFE) {
+        const f2 q = div2_u16(n, f2{f32.v[2 * p], f32.v[2 * p + 1]});  // positive; saturated when packed or below
+        out[2 * p] = min((unsigned int)q.x, 65535u);
+        out[2 * p + 1] = min((unsigned int)q.y, 65535u);
+      } else {
+        out[2 * p] = (unsigned int)fminf(fmaxf(MS_FDIV(n.x, f32.v[2 * p]), 0.0f), 65535.0f);
+        out[2 * p + 1] = (unsigned int)fminf(fmaxf(MS_FDIV(n.y, f32.v[2 * p + 1]), 0.0f), 65535.0f);
+      }
+    } else if constexpr (FF == MISTITCH_FF_F64) {
+      out[2 * p] = (unsigned int)fmin(fmax((double)(d & 0xffffu) / f64.v[2 * p], 0.0), 65535.0);
+      out[2 * p + 1] = (unsigned int)fmin(fmax((double)(d >> 16) / f64.v[2 * p + 1], 0.0), 65535.0);
+    } else {
+      out[2 * p] = d & 0xffffu;
+      out[2 * p + 1] = d >> 16;
+    }
+  }
+}
+
+// Two values to one dword of pixels; values above 65535 saturate.
+__device__ __forceinline__ unsigned pack2(unsigned lo, unsigned hi) {
+  typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+  const us2 pk = __builtin_amdgcn_cvt_pk_u16(lo, hi);
+  return __builtin_bit_cast(unsigned, pk);
+}
+
+template <int FF, bool SAFE>
+__device__ __forceinline__ Px8 corrected8_packed(const Px8& v, const F8& f32, const D8& f64) {
+  if constexpr (FF == MISTITCH_FF_F32 && SAFE) {
+    Px8 o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const unsigned d = v.d[p];
+      const f2 n = {(float)(d & 0xffffu), (float)(d >> 16)};
+      const f2 q = div2_u16(n, f2{f32.v[2 * p], f32.v[2 * p + 1]});
+      o.d[p] = pack2((unsigned int)q.x, (unsigned int)q.y);
+    }
+    return o;
+  } else {
+    unsigned u[8];
+    corrected8<FF, SAFE>(v, f32, f64, u);
+    Px8 o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) o.d[p] = u[2 * p] | (u[2 * p + 1] << 16);
+    return o;
+  }
+}
+
+// Feather blend of one group that `cnt` (2 or 3) tiles cover completely, all with a
+// usable flatfield plane: loads of all sources issued together, float32 operations
+// rounded one by one in placement order (two pixels per instruction).  `idx` holds
+// the candidate indices, 5 bits each, the LAST placed in the lowest bits.
+template <int FF, bool SAFE>
+__device__ __forceinline__ Px8 blend_group(int y, int x, int cnt, unsigned idx, const TileRef* list,
+                                           const uint16_t* __restrict__ tiles, int H, int W,
+                                           const void* __restrict__ flatfields) {
+  constexpr size_t ffsize = FF == MISTITCH_FF_F64 ? 8 : 4;
+  Px8 sv[3];
+  F8 sf32[FF == MISTITCH_FF_F32 ? 3 : 1];
+  D8 sf64[FF == MISTITCH_FF_F64 ? 3 : 1];
+  int lys[3], lxs[3];
+  const int64_t at = (int64_t)y * W + x;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int shift = 5 * (cnt - 1 - (q < cnt ? q : 0));  // an absent third source re-reads the first
+    const TileRef c = list[(idx >> shift) & 31u];
+    lys[q] = y - c.ty;
+    lxs[q] = x - c.tx;
+    sv[q] = *reinterpret_cast<const Px8*>(tiles + (c.src_base + at));
+    if constexpr (FF == MISTITCH_FF_F32)
+      sf32[q] = *reinterpret_cast<const F8*>(reinterpret_cast<const char*>(flatfields) + (c.ff_base + at) * (int64_t)ffsize);
+    if constexpr (FF == MISTITCH_FF_F64)
+      sf64[q] = *reinterpret_cast<const D8*>(reinterpret_cast<const char*>(flatfields) + (c.ff_base + at) * (int64_t)ffsize);
+  }
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    MS_PIN_PX8(sv[q]);
+    if constexpr (FF == MISTITCH_FF_F32) MS_PIN_8(sf32[q]);
+    if constexpr (FF == MISTITCH_FF_F64) MS_PIN_8(sf64[q]);
+  }
+  f2 num[4], den[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) num[p] = den[p] = f2{0.0f, 0.0f};
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    if (q < 2 || cnt == 3) {
+      const float wy = (float)min(lys[q] + 1, H - lys[q]);
+      const float a = (float)(lxs[q] + 1), b = (float)(W - lxs[q]);  // ramp from the left / right tile edge
+      unsigned u[8];
+      corrected8<FF, SAFE>(sv[q], sf32[FF == MISTITCH_FF_F32 ? q : 0], sf64[FF == MISTITCH_FF_F64 ? q : 0], u);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const f2 val = {(float)u[2 * p], (float)u[2 * p + 1]};
+        const f2 up = f2{a, a} + f2{(float)(2 * p), (float)(2 * p + 1)};
+        const f2 down = f2{b, b} - f2{(float)(2 * p), (float)(2 * p + 1)};
+        const f2 w = f2{wy, wy} * f2{fminf(up.x, down.x), fminf(up.y, down.y)};
+        num[p] = num[p] + w * val;
+        den[p] = den[p] + w;
+      }
+    }
+  }
+  Px8 o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const f2 t = div2_noscale(num[p], den[p]) + f2{0.5f, 0.5f};  // floor(t) by the truncating conversion: t > 0
+    o.d[p] = pack2((unsigned int)t.x, (unsigned int)t.y);
+  }
+  return o;
+}
+
+// Work of one block.  1-D grid of 8 * gx * ceil(gy * n_planes / 8) workgroups with
 // gx = ceil(ceil((Wm + 7) / 8) / (64 GX)) and gy = ceil((row1 - row0) / kBH).
 // GX = 16-byte groups per lane along a row: a wave moves GX KiB of one mosaic row per step.
-template <int MODE, int FF, int GX>
-__global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restrict__ tiles, int n_tiles, int H,
-                                                       int W, int64_t tile_pitch,
-                                                       const int32_t* __restrict__ tile_yx,
-                                                       const int32_t* __restrict__ tile_plane,
-                                                       const void* __restrict__ flatfields,
-                                                       const int32_t* __restrict__ tile_ff,
-                                                       const int32_t* __restrict__ bins,
-                                                       uint16_t* __restrict__ mosaic, int Hm, int Wm, int row0,
-                                                       int row1, int gx, int gy, int n_planes) {
-  __shared__ TileRef list[kMaxCand];
-  __shared__ uint16_t queue[kBH * 64 * GX];  // (row in block << 8) | group in block row
-  __shared__ unsigned queue_len;
+//
+// Queue entries (one 32-bit word per group that is not a plain copy):
+//   bits 0-7 group in the block row, 8-12 row in the block, 13-14 number of blended
+//   sources (0: resolve pixel by pixel), 15-29 their candidate indices, 5 bits each.
+// Blend entries fill the queue from the bottom, pixel-by-pixel entries from the top.
+template <int MODE, int FF, int GX, bool SAFE>
+__device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsigned* queue_len,
+                                           const uint16_t* __restrict__ tiles, int n_tiles, int H, int W,
+                                           int64_t tile_pitch, const int32_t* __restrict__ tile_yx,
+                                           const int32_t* __restrict__ tile_plane,
+                                           const void* __restrict__ flatfields,
+                                           const int32_t* __restrict__ tile_ff, const int32_t* __restrict__ bins,
+                                           uint16_t* __restrict__ mosaic, int Hm, int Wm, int row0, int row1, int gx,
+                                           int gy, int n_planes) {
+  constexpr int kQueue = kBH * 64 * GX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) queue_len = 0;
+  if (tid == 0) queue_len[0] = queue_len[1] = 0;
   // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  All
   // blocks of one block-row read the same flatfield rows (the tiles of a grid row
   // start at nearly the same y), so a whole block-row is given to ONE XCD: block-row
@@ -381,74 +469,84 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
   // the tiles touching this block, in placement order, were listed by k_fuse_bins
   const int32_t* bin = bins + ((int64_t)rid * gx + bx) * (kMaxCand + 1);
   const int total = bin[0];
+  bool has_ff = false;
   if (tid < total && tid < kMaxCand) {
-    const int t = bin[1 + tid];
-    list[tid] = TileRef{tile_yx[2 * t], tile_yx[2 * t + 1], t, tile_ff ? tile_ff[t] : -1};
+    const TileRef c = make_ref(bin[1 + tid], tile_yx, tile_ff, H, W, tile_pitch);
+    list[tid] = c;
+    has_ff = c.ff >= 0;
   }
+  // candidates that a plain copy or a batched blend can take: with a flatfield kernel, those that have a plane
+  const unsigned okmask = FF == MISTITCH_FF_NONE ? 0xffffffffu : (unsigned)__ballot(has_ff && wave == 0);
+  if (tid == 0) queue_len[2] = okmask;
   __syncthreads();
-  const bool overflow = total > kMaxCand;  // fall back to scanning every tile per group
+  const unsigned ffok = queue_len[2];
+  // more tiles than the list holds, or tiles or a mosaic narrower than a group: every group is resolved pixel by pixel
+  const bool overflow = total > kMaxCand;
+  const bool generic_only = overflow || W < 8 || Wm < 8;
   const int ncand = overflow ? n_tiles : total;
   uint16_t* mplane = mosaic + (int64_t)plane * Hm * Wm;
   const int w_idx = bx * (64 * GX) + lane;  // first aligned group of this lane within a row
   constexpr size_t ffsize = FF == MISTITCH_FF_F64 ? 8 : 4;
 
-  // One mosaic row per wave and step.  A lane first classifies its GX groups
-  // without touching pixel memory (0: uncovered, 1: plain copy from one tile,
-  // 2: anything else), issues all copy loads back to back and stores.
+  // One mosaic row per wave and step.  The tiles whose rows include y are found once
+  // per row (one candidate per lane, a ballot); a lane then classifies its GX groups
+  // against those few without touching pixel memory (0: uncovered, 1: plain copy from
+  // one tile, 2: queued, 3: outside the mosaic), issues all copy loads back to back
+  // and stores.
   for (int y = y0 + wave; y < y1; y += kFuseThreads / 64) {
     uint16_t* rowp = mplane + (int64_t)y * Wm;
     const int a = (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
+    const int64_t yW = (int64_t)y * W;
+    unsigned ymask = 0;
+    if (!generic_only) {
+      const bool in_rows = lane < ncand && (unsigned)(y - list[lane & (kMaxCand - 1)].ty) < (unsigned)H;
+      ymask = (unsigned)__ballot(in_rows);
+    }
+    const int x0 = 8 * w_idx - a;
+    int cnt[GX];
+    unsigned idx[GX];    // touching candidates, 5 bits each, the last placed in the lowest bits
+    bool bad[GX];        // some touching tile covers the group only partly or lacks a flatfield plane
+    bool last_bad[GX];   // the same for the last placed touching tile alone
+#pragma unroll
+    for (int r = 0; r < GX; ++r) {
+      cnt[r] = 0;
+      idx[r] = 0;
+      bad[r] = last_bad[r] = false;
+    }
+    for (unsigned m = ymask; m; m &= m - 1u) {  // wave-uniform loop over the row's tiles
+      const int ci = __builtin_ctz(m);
+      const int tx = list[ci].tx;
+      const bool not_ok = !((ffok >> ci) & 1u);
+#pragma unroll
+      for (int r = 0; r < GX; ++r) {
+        const int lx0 = x0 + 512 * r - tx;
+        const bool touch = (unsigned)(lx0 + 7) < (unsigned)(W + 7);
+        const bool part = ((unsigned)lx0 > (unsigned)(W - 8)) | not_ok;
+        idx[r] = touch ? ((idx[r] << 5) | (unsigned)ci) : idx[r];
+        cnt[r] += touch ? 1 : 0;
+        bad[r] = bad[r] | (touch & part);
+        last_bad[r] = touch ? part : last_bad[r];
+      }
+    }
     Px8 v[GX];
     F8 f32[FF == MISTITCH_FF_F32 ? GX : 1];
     D8 f64[FF == MISTITCH_FF_F64 ? GX : 1];
     unsigned kinds = 0;  // two bits per group
 #pragma unroll
     for (int r = 0; r < GX; ++r) {
-      const int x = 8 * (w_idx + 64 * r) - a;
-      unsigned vm = 0;
-      if (x + 8 > 0 && x < Wm) vm = (((1u << min(8, Wm - x)) - 1u) & ~((1u << max(0, -x)) - 1u)) & 0xffu;
-      int k = vm ? 0 : 3, sel = 0;  // 3: nothing to write
-      if (vm && overflow) k = 2;
-      if (vm && !overflow) {
-        if constexpr (MODE == MISTITCH_FUSE_OVERWRITE) {
-          for (int ci = ncand - 1; ci >= 0; --ci) {  // the latest tile that touches the group decides
-            const TileRef c = list[ci];
-            const int ly = y - c.ty, lx0 = x - c.tx;
-            if ((unsigned)ly >= (unsigned)H) continue;
-            const int lo = max(0, -lx0), hi = min(8, W - lx0);
-            if (lo >= hi) continue;
-            if (!((((1u << hi) - 1u) & ~((1u << lo) - 1u)) & vm)) continue;
-            k = (lo == 0 && hi == 8 && vm == 0xffu && (FF == MISTITCH_FF_NONE || c.ff >= 0)) ? 1 : 2;
-            sel = ci;
-            break;
-          }
-        } else {
-          int touching = 0;
-          bool simple = vm == 0xffu;
-          for (int ci = 0; ci < ncand; ++ci) {
-            const TileRef c = list[ci];
-            const int ly = y - c.ty, lx0 = x - c.tx;
-            if ((unsigned)ly >= (unsigned)H) continue;
-            const int lo = max(0, -lx0), hi = min(8, W - lx0);
-            if (lo >= hi) continue;
-            if (!((((1u << hi) - 1u) & ~((1u << lo) - 1u)) & vm)) continue;
-            ++touching;
-            sel = ci;
-            simple = simple && lo == 0 && hi == 8 && (FF == MISTITCH_FF_NONE || c.ff >= 0);
-          }
-          if (touching == 1 && simple) k = 1;
-          else if (touching >= 1) k = 2;
-        }
-      }
+      const int x = x0 + 512 * r;
+      const bool outside = !((unsigned)(x + 7) < (unsigned)(Wm + 7));
+      const bool inside = (unsigned)x <= (unsigned)(Wm - 8);  // not cut by the mosaic edge
+      const bool copy = MODE == MISTITCH_FUSE_OVERWRITE ? !last_bad[r] : (cnt[r] == 1) & !bad[r];
+      int k = (cnt[r] == 0) ? 0 : (copy ? 1 : 2);
+      k = (!inside | generic_only) ? 2 : k;
+      k = outside ? 3 : k;
       kinds |= (unsigned)k << (2 * r);
       // copy loads never sit behind a branch: lanes without a plain copy read tile 0's first pixels
-      int64_t off = 0, foff = 0;
-      if (k == 1) {
-        const TileRef c = list[sel];
-        const int64_t in_tile = (int64_t)(y - c.ty) * W + (x - c.tx);
-        off = (int64_t)c.t * tile_pitch + in_tile;
-        foff = (int64_t)c.ff * H * W + in_tile;
-      }
+      const TileRef* c = list + (idx[r] & 31u);
+      const int64_t at = yW + x;
+      const int64_t off = k == 1 ? c->src_base + at : 0;
+      const int64_t foff = k == 1 ? c->ff_base + at : 0;
       v[r] = *reinterpret_cast<const Px8*>(tiles + off);
       if constexpr (FF == MISTITCH_FF_F32)
         f32[r] = *reinterpret_cast<const F8*>(reinterpret_cast<const char*>(flatfields) + foff * (int64_t)ffsize);
@@ -464,75 +562,146 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
 #pragma unroll
     for (int r = 0; r < GX; ++r) {
       const unsigned k = (kinds >> (2 * r)) & 3u;
-      if (k >= 2) continue;
-      const int x = 8 * (w_idx + 64 * r) - a;
-      uint16_t px[8];
+      const int x = x0 + 512 * r;
       if (k == 1) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if constexpr (FF == MISTITCH_FF_F32) {
-            float q = __fdiv_rn((float)v[r].at(i), f32[r].v[i]);
-            q = fminf(fmaxf(q, 0.0f), 65535.0f);
-            px[i] = (uint16_t)(unsigned int)q;
-          } else if constexpr (FF == MISTITCH_FF_F64) {
-            double q = (double)v[r].at(i) / f64[r].v[i];
-            q = fmin(fmax(q, 0.0), 65535.0);
-            px[i] = (uint16_t)(unsigned int)q;
-          } else {
-            px[i] = (uint16_t)v[r].at(i);
-          }
+        if constexpr (FF == MISTITCH_FF_NONE)
+          *reinterpret_cast<Px8*>(rowp + x) = v[r];
+        else
+          *reinterpret_cast<Px8*>(rowp + x) = corrected8_packed<FF, SAFE>(v[r], f32[FF == MISTITCH_FF_F32 ? r : 0],
+                                                                           f64[FF == MISTITCH_FF_F64 ? r : 0]);
+      } else if (k == 0) {
+        *reinterpret_cast<Px8*>(rowp + x) = Px8{{0u, 0u, 0u, 0u}};
+      } else if (k == 2) {
+        // queued for the whole workgroup: these groups cluster in the overlap bands, and
+        // handled in place they would stall every wave that owns a few
+        unsigned e = (unsigned)(lane + 64 * r) | ((unsigned)(y - y0) << 8);
+        const bool inside = (unsigned)x <= (unsigned)(Wm - 8);
+        const bool blend = MODE == MISTITCH_FUSE_FEATHER && !generic_only && inside && !bad[r] && cnt[r] >= 2 &&
+                           cnt[r] <= 3;
+        if (blend) {
+          e |= ((unsigned)cnt[r] << 13) | (idx[r] << 15);
+          queue[atomicAdd(&queue_len[0], 1u)] = e;
+        } else {
+          queue[kQueue - 1 - atomicAdd(&queue_len[1], 1u)] = e;
         }
-        store_window(rowp + x, px, 0xffu);
-      } else {
-        unsigned vm = (((1u << min(8, Wm - x)) - 1u) & ~((1u << max(0, -x)) - 1u)) & 0xffu;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) px[i] = 0;
-        store_window(rowp + x, px, vm);
-      }
-    }
-    // groups of the last kind are queued for the whole workgroup: they cluster in the
-    // overlap bands, and handled in place they would stall every wave that owns a few
-#pragma unroll
-    for (int r = 0; r < GX; ++r) {
-      if (((kinds >> (2 * r)) & 3u) == 2u) {
-        const unsigned slot = atomicAdd(&queue_len, 1u);
-        queue[slot] = (uint16_t)(((y - y0) << 8) | (lane + 64 * r));
       }
     }
   }
   __syncthreads();
-  const unsigned n_slow = queue_len;
-  for (unsigned i = tid; i < n_slow; i += kFuseThreads) {
-    const unsigned e = queue[i];
-    const int y = y0 + (int)(e >> 8);
+  if constexpr (MODE == MISTITCH_FUSE_FEATHER) {
+    const unsigned n_blend = queue_len[0];
+    for (unsigned i = tid; i < n_blend; i += kFuseThreads) {
+      const unsigned e = queue[i];
+      const int y = y0 + (int)((e >> 8) & 31u);
+      uint16_t* rowp = mplane + (int64_t)y * Wm;
+      const int a = (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
+      const int x = 8 * (bx * (64 * GX) + (int)(e & 0xffu)) - a;
+      *reinterpret_cast<Px8*>(rowp + x) =
+          blend_group<FF, SAFE>(y, x, (int)((e >> 13) & 3u), (e >> 15) & 0x7fffu, list, tiles, H, W, flatfields);
+    }
+  }
+  const unsigned n_generic = queue_len[1];
+  for (unsigned i = tid; i < n_generic; i += kFuseThreads) {
+    const unsigned e = queue[kQueue - 1 - i];
+    const int y = y0 + (int)((e >> 8) & 31u);
     uint16_t* rowp = mplane + (int64_t)y * Wm;
     const int a = (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
     const int x = 8 * (bx * (64 * GX) + (int)(e & 0xffu)) - a;
     const unsigned vm = (((1u << min(8, Wm - x)) - 1u) & ~((1u << max(0, -x)) - 1u)) & 0xffu;
     uint16_t px[8];
-    slow_window<MODE, FF>(y, x, vm, list, ncand, overflow, plane, tiles, H, W, tile_pitch, tile_yx, tile_plane,
-                          flatfields, tile_ff, px);
+    resolve_window<MODE, FF>(y, x, vm, list, ncand, overflow, plane, tiles, H, W, tile_pitch, tile_yx, tile_plane,
+                             flatfields, tile_ff, px);
     store_window(rowp + x, px, vm);
   }
 }
 
-// out = trunc(clip(in / ff)); one flatfield plane shared by n_tiles images.
+// `ff_safe` points at the verdict of k_ff_check (1: every flatfield value used by this
+// call admits the scaling-free division).
+template <int MODE, int FF, int GX>
+__global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restrict__ tiles, int n_tiles, int H,
+                                                       int W, int64_t tile_pitch,
+                                                       const int32_t* __restrict__ tile_yx,
+                                                       const int32_t* __restrict__ tile_plane,
+                                                       const void* __restrict__ flatfields,
+                                                       const int32_t* __restrict__ tile_ff,
+                                                       const int32_t* __restrict__ bins,
+                                                       const int32_t* __restrict__ ff_safe,
+                                                       uint16_t* __restrict__ mosaic, int Hm, int Wm, int row0,
+                                                       int row1, int gx, int gy, int n_planes) {
+  __shared__ TileRef list[kMaxCand];
+  __shared__ unsigned queue[kBH * 64 * GX];
+  __shared__ unsigned queue_len[3];  // blend entries, pixel-by-pixel entries, candidates with a flatfield plane
+  if constexpr (FF == MISTITCH_FF_F32) {
+    if (*ff_safe) {
+      fuse_block<MODE, FF, GX, true>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
+                                     flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes);
+      return;
+    }
+  }
+  fuse_block<MODE, FF, GX, false>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
+                                  flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes);
+}
+
+// Are all float32 flatfield values that this call uses finite and within [2^-16, 2^16]?
+// grid (kFfChunks, kFfPlanes): block (c, p) looks whether any tile uses plane p and, if
+// so, scans chunk c of it; a violation (or a plane index >= kFfPlanes) clears *verdict,
+// which has been set nonzero before (k_fuse_bins, or a memset).
+constexpr int kFfChunks = 512, kFfPlanes = 64;
+__global__ __launch_bounds__(256) void k_ff_check(const float* __restrict__ flatfields,
+                                                  const int32_t* __restrict__ tile_ff, int n_tiles, int64_t plane_px,
+                                                  int32_t* verdict) {
+  const int p = blockIdx.y;
+  int used = 0, beyond = 0;
+  if (!tile_ff) used = p == 0;  // a single plane
+  for (int t = threadIdx.x; tile_ff && t < n_tiles; t += blockDim.x) {
+    const int f = tile_ff[t];
+    used |= f == p;
+    beyond |= f >= kFfPlanes;
+  }
+  used = __syncthreads_or(used);
+  beyond = __syncthreads_or(beyond);
+  if (beyond && threadIdx.x == 0 && blockIdx.x == 0 && p == 0) *verdict = 0;
+  if (!used) return;
+  const float* plane = flatfields + (int64_t)p * plane_px;
+  const int64_t per = ((plane_px + kFfChunks - 1) / kFfChunks + 3) & ~(int64_t)3;
+  const int64_t i0 = per * blockIdx.x, i1 = min(plane_px, i0 + per);
+  int bad = 0;
+  // positive, exponent within +-16: bits in [0x37800000, 0x47800000]
+  for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 4 * blockDim.x) {
+    if (i + 4 <= i1) {
+      const F8* q = reinterpret_cast<const F8*>(plane + i);  // 4-byte aligned 16-byte read of the first half
+      const float a = q->v[0], b = q->v[1], c = q->v[2], d = q->v[3];
+      const unsigned worst = max(max(__float_as_uint(a) - 0x37800000u, __float_as_uint(b) - 0x37800000u),
+                                 max(__float_as_uint(c) - 0x37800000u, __float_as_uint(d) - 0x37800000u));
+      bad |= worst > 0x10000000u;
+    } else {
+      for (int64_t e = i; e < i1; ++e) bad |= !(__float_as_uint(plane[e]) - 0x37800000u <= 0x10000000u);
+    }
+  }
+  if (__syncthreads_or(bad) && threadIdx.x == 0) *verdict = 0;
+}
+
+// out = trunc(clip(in / ff)); one flatfield plane shared by n_tiles images.  One
+// 8-pixel group per thread, bpt blocks per tile; the tail (n_px_per_tile % 8) is
+// handled by k_flatfield_tail.  `ff_safe`: verdict of k_ff_check for the plane.
 template <int FF>
 __global__ __launch_bounds__(256) void k_flatfield(const uint16_t* in, const void* __restrict__ ff, uint16_t* out,
-                                                   int64_t n_px_per_tile, int64_t n_groups) {
-  // n_groups = n_tiles * (n_px_per_tile / 8); the tail (n_px_per_tile % 8) is handled by k_flatfield_tail
-  const int64_t gpt = n_px_per_tile / 8;
-  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n_groups; g += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t t = g / gpt, q = g - t * gpt;
-    const uint16_t* src = in + t * n_px_per_tile + q * 8;
-    uint16_t px[8];
-    const char* ffrow = reinterpret_cast<const char*>(ff) + q * 8 * (FF == MISTITCH_FF_F64 ? 8 : 4);
-    fetch_window<FF>(src, ffrow, 0xffu, px);
-    Px8 o;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) o.d[i] = px[2 * i] | ((unsigned)px[2 * i + 1] << 16);
-    *reinterpret_cast<Px8*>(out + t * n_px_per_tile + q * 8) = o;
-  }
+                                                   int64_t n_px_per_tile, unsigned bpt, unsigned tile0,
+                                                   const int32_t* __restrict__ ff_safe) {
+  const unsigned t = tile0 + blockIdx.x / bpt;
+  const int64_t q = (int64_t)(blockIdx.x % bpt) * 256 + threadIdx.x;
+  if (q >= n_px_per_tile / 8) return;
+  const Px8 v = *reinterpret_cast<const Px8*>(in + t * n_px_per_tile + q * 8);
+  F8 f32{};
+  D8 f64{};
+  if constexpr (FF == MISTITCH_FF_F32) f32 = *reinterpret_cast<const F8*>(reinterpret_cast<const float*>(ff) + q * 8);
+  if constexpr (FF == MISTITCH_FF_F64) f64 = *reinterpret_cast<const D8*>(reinterpret_cast<const double*>(ff) + q * 8);
+  Px8 o;
+  if (FF == MISTITCH_FF_F32 && *ff_safe)
+    o = corrected8_packed<FF, FF == MISTITCH_FF_F32>(v, f32, f64);
+  else
+    o = corrected8_packed<FF, false>(v, f32, f64);
+  *reinterpret_cast<Px8*>(out + t * n_px_per_tile + q * 8) = o;
 }
 
 template <int FF>
@@ -572,12 +741,13 @@ __global__ __launch_bounds__(256) void k_mip(const uint16_t* __restrict__ in, in
 template <int MODE, int FF, int GX>
 static void launch_fuse(mistitch_ctx* ctx, dim3 grid, const uint16_t* tiles, int n_tiles, int H, int W, int64_t pitch,
                         const int32_t* yx, const int32_t* plane, const void* ffs, const int32_t* tff,
-                        const int32_t* bins, uint16_t* mosaic, int Hm, int Wm, int row0, int row1) {
+                        const int32_t* bins, const int32_t* ff_safe, uint16_t* mosaic, int Hm, int Wm, int row0,
+                        int row1) {
   const int gx = (int)grid.x, gy = (int)grid.y, n_planes = (int)grid.z;
   const unsigned n_wg = 8u * gx * (unsigned)((gy * n_planes + 7) / 8);
   MS_LAUNCH(ctx, MODE == MISTITCH_FUSE_OVERWRITE ? "k_fuse_overwrite" : "k_fuse_feather", (k_fuse<MODE, FF, GX>),
-            dim3(n_wg), dim3(kFuseThreads), 0, tiles, n_tiles, H, W, pitch, yx, plane, ffs, tff, bins, mosaic, Hm, Wm,
-            row0, row1, gx, gy, n_planes);
+            dim3(n_wg), dim3(kFuseThreads), 0, tiles, n_tiles, H, W, pitch, yx, plane, ffs, tff, bins, ff_safe, mosaic,
+            Hm, Wm, row0, row1, gx, gy, n_planes);
 }
 
 }  // namespace mistitch
@@ -607,14 +777,19 @@ extern "C" int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_til
   MS_REQUIRE((int64_t)grid.x * grid.y * grid.z < (1ll << 30), MISTITCH_ERR_UNSUPPORTED, "mosaic too large for one launch");
   const int64_t n_blocks = (int64_t)grid.x * grid.y * grid.z;
   int rc;
-  if ((rc = ctx->bins.reserve((size_t)n_blocks * (kMaxCand + 1) * sizeof(int32_t)))) return rc;
+  const size_t bins_bytes = (size_t)n_blocks * (kMaxCand + 1) * sizeof(int32_t);
+  if ((rc = ctx->bins.reserve(bins_bytes + 16))) return rc;
   const int32_t* bins = reinterpret_cast<const int32_t*>(ctx->bins.ptr);
+  int32_t* ff_safe = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ctx->bins.ptr) + bins_bytes);
   MS_LAUNCH(ctx, "k_fuse_bins", k_fuse_bins, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, n_tiles, tile_h, tile_w,
             tile_yx, tile_plane, reinterpret_cast<int32_t*>(ctx->bins.ptr), (int)grid.x, (int)grid.y, n_planes, mosaic_w,
-            row0, row1, 512 * GX);
+            row0, row1, 512 * GX, ff_safe);
+  if (ff_type == MISTITCH_FF_F32 && n_tiles > 0)
+    MS_LAUNCH(ctx, "k_ff_check", k_ff_check, dim3(kFfChunks, kFfPlanes), dim3(256), 0,
+              reinterpret_cast<const float*>(flatfields), tile_ff, n_tiles, (int64_t)tile_h * tile_w, ff_safe);
 #define MS_FUSE(M, F)                                                                                          \
   launch_fuse<M, F, (F == MISTITCH_FF_NONE ? kGxPlain : kGxFlat)>(ctx, grid, tiles, n_tiles, tile_h, tile_w, tile_pitch, tile_yx, tile_plane, flatfields, tile_ff, \
-                    bins, mosaic, mosaic_h, mosaic_w, row0, row1)
+                    bins, ff_safe, mosaic, mosaic_h, mosaic_w, row0, row1)
   if (mode == MISTITCH_FUSE_OVERWRITE) {
     if (ff_type == MISTITCH_FF_NONE) MS_FUSE(MISTITCH_FUSE_OVERWRITE, MISTITCH_FF_NONE);
     else if (ff_type == MISTITCH_FF_F32) MS_FUSE(MISTITCH_FUSE_OVERWRITE, MISTITCH_FF_F32);
@@ -638,15 +813,30 @@ extern "C" int mistitch_apply_flatfield(mistitch_ctx* ctx, const uint16_t* in, c
   if (n_tiles == 0) return MISTITCH_OK;
   MS_HIP(hipSetDevice(ctx->device));
   const int64_t npx = (int64_t)tile_h * tile_w;
-  const int64_t groups = (npx / 8) * n_tiles;
-  const int blocks = (int)std::min<int64_t>((groups + 255) / 256, 256 * 16);
+  const int64_t gpt = npx / 8;
+  const unsigned bpt = (unsigned)((gpt + 255) / 256);
   const int ntail = (int)(npx % 8) * n_tiles;
+  int rc;
+  if ((rc = ctx->flags.reserve(16))) return rc;
+  int32_t* ff_safe = reinterpret_cast<int32_t*>(ctx->flags.ptr);
   if (ff_type == MISTITCH_FF_F32) {
-    if (groups) MS_LAUNCH(ctx, "k_flatfield", k_flatfield<MISTITCH_FF_F32>, dim3(blocks), dim3(256), 0, in, flatfield, out, npx, groups);
-    if (ntail) MS_LAUNCH(ctx, "k_flatfield_tail", k_flatfield_tail<MISTITCH_FF_F32>, dim3((ntail + 63) / 64), dim3(64), 0, in, flatfield, out, npx, n_tiles);
-  } else {
-    if (groups) MS_LAUNCH(ctx, "k_flatfield", k_flatfield<MISTITCH_FF_F64>, dim3(blocks), dim3(256), 0, in, flatfield, out, npx, groups);
-    if (ntail) MS_LAUNCH(ctx, "k_flatfield_tail", k_flatfield_tail<MISTITCH_FF_F64>, dim3((ntail + 63) / 64), dim3(64), 0, in, flatfield, out, npx, n_tiles);
+    MS_HIP(hipMemsetAsync(ff_safe, 1, sizeof(int32_t), ctx->stream));
+    MS_LAUNCH(ctx, "k_ff_check", k_ff_check, dim3(kFfChunks, 1), dim3(256), 0, reinterpret_cast<const float*>(flatfield),
+              (const int32_t*)nullptr, 0, npx, ff_safe);
+  }
+  const unsigned tiles_per_launch = bpt ? std::max(1u, 0x7fffffffu / bpt) : 1u;
+  for (unsigned t0 = 0; gpt && t0 < (unsigned)n_tiles; t0 += tiles_per_launch) {
+    const unsigned nt = std::min(tiles_per_launch, (unsigned)n_tiles - t0);
+    if (ff_type == MISTITCH_FF_F32)
+      MS_LAUNCH(ctx, "k_flatfield", k_flatfield<MISTITCH_FF_F32>, dim3(nt * bpt), dim3(256), 0, in, flatfield, out, npx, bpt, t0, ff_safe);
+    else
+      MS_LAUNCH(ctx, "k_flatfield", k_flatfield<MISTITCH_FF_F64>, dim3(nt * bpt), dim3(256), 0, in, flatfield, out, npx, bpt, t0, ff_safe);
+  }
+  if (ntail) {
+    if (ff_type == MISTITCH_FF_F32)
+      MS_LAUNCH(ctx, "k_flatfield_tail", k_flatfield_tail<MISTITCH_FF_F32>, dim3((ntail + 63) / 64), dim3(64), 0, in, flatfield, out, npx, n_tiles);
+    else
+      MS_LAUNCH(ctx, "k_flatfield_tail", k_flatfield_tail<MISTITCH_FF_F64>, dim3((ntail + 63) / 64), dim3(64), 0, in, flatfield, out, npx, n_tiles);
   }
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;

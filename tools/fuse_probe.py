@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--tile", type=int, default=2048)
     ap.add_argument("--channels", type=int, default=4)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--overlap", type=float, default=0.1)
+    ap.add_argument("--jitter", type=int, default=7)
     args = ap.parse_args()
     import torch
     from image_stitcher_amd import _lib, synth
@@ -23,9 +25,9 @@ def main():
 
     dev = torch.device("cuda", 0)
     t, ch, n = args.tile, args.channels, args.rows * args.cols
-    pitch = t - int(round(t * 0.1))
+    pitch = t - int(round(t * args.overlap))
     rng = np.random.default_rng(0)
-    yx = np.array([[r * pitch + rng.integers(0, 7), c * pitch + rng.integers(0, 7)]
+    yx = np.array([[r * pitch + rng.integers(0, args.jitter), c * pitch + rng.integers(0, args.jitter)]
                    for r in range(args.rows) for c in range(args.cols)], dtype=np.int32)
     mh, mw = int(yx[:, 0].max()) + t, int(yx[:, 1].max()) + t
     tiles = torch.randint(0, 30000, (ch * n, t, t), dtype=torch.int16, device=dev).view(torch.uint16)
