@@ -156,5 +156,6 @@ struct mistitch_ctx {
   std::set<const void*> lds_enabled;  // kernels already granted large dynamic LDS
   std::map<long long, std::vector<char>> shapes;  // cached per-strip-shape launch configuration
   std::vector<void*> shape_allocs;                // device tables owned by those configurations
+  std::map<int, std::vector<char>> gen_plans;     // chirp-z plans by transform length
   mistitch::Profiler prof;
 };

@@ -618,6 +618,180 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   MS_STAMP(2, 3);
 }
 
+// ---------------------------------------------------------------------------
+// Strips whose sides are not powers of two: chirp-z (Bluestein) transforms built on
+// the power-of-two engine, complex128 throughout, the whole (non-Hermitian) plane.
+//   X[k] = c[k] * sum_j (x[j] c[j]) b[k - j],  c[j] = exp(-i pi j^2 / n),  b[m] = conj(c[|m|])
+// The convolution runs as a length-M FFT (M = power of two >= 2n - 1) against the
+// precomputed transform of b, stored in the engine's digit-reversed order and
+// already divided by M.  The inverse transform conjugates c and b's transform.
+struct GenPlanDev {
+  int n, M;
+  FftPlanDev planM;
+  const double2* chirp;  // [n]
+  const double2* bhat;   // [M], position order
+};
+
+// Transform nl lines of length n held in LDS (line f, element i at addr(f, i); the
+// line has room for M elements), in place.  Block synchronised on entry and exit.
+__device__ __forceinline__ void bluestein_lines(double2* buf, const LineAddr<double>& addr, int nl, const GenPlanDev& gp,
+                                                const Twiddles<double>& tw, bool inverse, int tid, int nthr) {
+  const int n = gp.n, M = gp.M;
+  for (int e = tid; e < nl * M; e += nthr) {
+    const int f = e / M, i = e - f * M;
+    const int a = addr(f, i);
+    if (i < n) {
+      double2 c = gp.chirp[i];
+      if (inverse) c.y = -c.y;
+      buf[a] = cmul(buf[a], c);
+    } else {
+      buf[a] = mk<double>(0.0, 0.0);
+    }
+  }
+  __syncthreads();
+  fft_forward<double>(buf, addr, nl, gp.planM, tw, tid, nthr);
+  for (int e = tid; e < nl * M; e += nthr) {
+    const int f = e / M, pos = e - f * M;
+    double2 h = gp.bhat[pos];
+    if (inverse) h.y = -h.y;
+    const int a = addr(f, pos);
+    buf[a] = cmul(buf[a], h);
+  }
+  __syncthreads();
+  fft_inverse<double>(buf, addr, nl, gp.planM, tw, tid, nthr);
+  for (int e = tid; e < nl * n; e += nthr) {
+    const int f = e / n, i = e - f * n;
+    double2 c = gp.chirp[i];
+    if (inverse) c.y = -c.y;
+    const int a = addr(f, i);
+    buf[a] = cmul(buf[a], c);
+  }
+  __syncthreads();
+}
+
+// z = a + i b per line, length-L transform, natural order out.  grid (S, pairs_in_pass).
+__global__ __launch_bounds__(kThreads) void k_gen_rows_fwd(const PairDesc* desc, const int8_t* status, int pair0, int S,
+                                                           int L, int want_transposed, GenPlanDev gp, double2* Zf) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double2* buf = reinterpret_cast<double2*>(smem_raw);
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  const int tid = threadIdx.x;
+  const LineAddr<double> addr{LineAddr<double>::padded(gp.M) + 1};
+  const Twiddles<double> tw = load_twiddles<double>(buf + addr.fstride, gp.planM, tid, kThreads);
+  const int s = blockIdx.x;
+  for (int i = tid; i < L; i += kThreads)
+    buf[addr(0, i)] = mk<double>((double)d.a[(int64_t)s * d.pitch + i], (double)d.b[(int64_t)s * d.pitch + i]);
+  __syncthreads();
+  bluestein_lines(buf, addr, 1, gp, tw, false, tid, kThreads);
+  double2* out = Zf + ((int64_t)blockIdx.y * S + s) * L;
+  for (int i = tid; i < L; i += kThreads) out[i] = buf[addr(0, i)];
+}
+
+// Length-S transform down C adjacent columns of the [S][L] plane, in place.
+// grid (ceil(L / C), pairs_in_pass).
+__global__ __launch_bounds__(kThreads) void k_gen_cols(const PairDesc* desc, const int8_t* status, int pair0, int S,
+                                                       int L, int want_transposed, GenPlanDev gp, int C, int inverse,
+                                                       double2* Z) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double2* buf = reinterpret_cast<double2*>(smem_raw);
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  {
+    const PairDesc& d = desc[p];
+    if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  }
+  const int tid = threadIdx.x;
+  const LineAddr<double> addr{LineAddr<double>::padded(gp.M) + 1};
+  const Twiddles<double> tw = load_twiddles<double>(buf + C * addr.fstride, gp.planM, tid, kThreads);
+  const int c0 = blockIdx.x * C;
+  const int nc = min(C, L - c0);
+  double2* plane = Z + (int64_t)blockIdx.y * S * L;
+  for (int e = tid; e < S * nc; e += kThreads) {
+    const int q = e / nc, c = e - q * nc;
+    buf[addr(c, q)] = plane[(int64_t)q * L + c0 + c];
+  }
+  __syncthreads();
+  bluestein_lines(buf, addr, nc, gp, tw, inverse != 0, tid, kThreads);
+  for (int e = tid; e < S * nc; e += kThreads) {
+    const int q = e / nc, c = e - q * nc;
+    plane[(int64_t)q * L + c0 + c] = buf[addr(c, q)];
+  }
+}
+
+// Normalised cross-power spectrum of the two real strips packed in Zf = F(a + i b).
+// grid (blocks, pairs_in_pass).
+__global__ __launch_bounds__(kThreads) void k_gen_cps(const PairDesc* desc, const int8_t* status, int pair0, int S,
+                                                      int L, int want_transposed, const double2* __restrict__ Zf,
+                                                      double2* __restrict__ R, double eps) {
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  {
+    const PairDesc& d = desc[p];
+    if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  }
+  const double2* zf = Zf + (int64_t)blockIdx.y * S * L;
+  double2* r = R + (int64_t)blockIdx.y * S * L;
+  for (int e = blockIdx.x * kThreads + threadIdx.x; e < S * L; e += gridDim.x * kThreads) {
+    const int q = e / L, c = e - q * L;
+    const double2 z = zf[e];
+    const double2 zm = zf[(int64_t)((S - q) % S) * L + (L - c) % L];
+    const double ax = 0.5 * (z.x + zm.x), ay = 0.5 * (z.y - zm.y);
+    const double bx = 0.5 * (z.y + zm.y), by = -0.5 * (z.x - zm.x);
+    double fx = ax * bx + ay * by;  // A * conj(B)
+    double fy = ay * bx - ax * by;
+    const double inv = 1.0 / (cabs_safe<double>(fx, fy) + eps);
+    r[e] = mk<double>(fx * inv, fy * inv);
+  }
+}
+
+// Inverse length-L transform of one line, scale, the line's k largest values.
+// grid (S, pairs_in_pass).
+__global__ __launch_bounds__(kThreads) void k_gen_rows_inv(const PairDesc* desc, const int8_t* status, int pair0, int S,
+                                                           int L, int want_transposed, GenPlanDev gp,
+                                                           const double2* __restrict__ R, int k, Peak* partial,
+                                                           int partial_stride, double* pcm_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double2* buf = reinterpret_cast<double2*>(smem_raw);
+  __shared__ Peak red[kThreads / 64];
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  const int tid = threadIdx.x;
+  const LineAddr<double> addr{LineAddr<double>::padded(gp.M) + 1};
+  const Twiddles<double> tw = load_twiddles<double>(buf + addr.fstride, gp.planM, tid, kThreads);
+  const int s = blockIdx.x;
+  const double2* in = R + ((int64_t)blockIdx.y * S + s) * L;
+  for (int i = tid; i < L; i += kThreads) buf[addr(0, i)] = in[i];
+  __syncthreads();
+  bluestein_lines(buf, addr, 1, gp, tw, true, tid, kThreads);
+  const double scale = 1.0 / ((double)S * (double)L);
+  if (pcm_out != nullptr) {
+    double* out = pcm_out + (int64_t)blockIdx.y * S * L;
+    for (int l = tid; l < L; l += kThreads)
+      out[d.transposed ? (int64_t)l * S + s : (int64_t)s * L + l] = buf[addr(0, l)].x * scale;
+  }
+  // k rounds of block argmax; a taken element is overwritten with -inf
+  for (int round = 0; round < k; ++round) {
+    Peak mine{-INFINITY, -1, -1};
+    for (int l = tid; l < L; l += kThreads) {
+      const int a0 = addr(0, l);
+      const double raw = buf[a0].x;
+      const int key = d.transposed ? l * S + s : s * L + l;
+      if (raw != -INFINITY && peak_better(raw * scale, key, mine.val, mine.key)) mine = Peak{raw * scale, key, a0};
+    }
+    const Peak best = block_argmax(mine, red);
+    if (tid == 0) {
+      partial[(int64_t)blockIdx.y * partial_stride + blockIdx.x * k + round] = best;
+      if (best.loc >= 0) buf[best.loc].x = -INFINITY;
+    }
+    __syncthreads();
+  }
+}
+
 // Merge the per-block peaks of one pair and emit the candidate table.
 // grid (n_pairs_in_pass), block kThreads.
 __global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* desc, const int8_t* status,
@@ -1065,7 +1239,7 @@ struct ShapeCfg {
 };
 
 constexpr size_t kLdsBudget = 64 * 1024;  // two blocks per CU
-constexpr size_t kLdsMax = 160 * 1024;
+constexpr size_t kLdsMax = 159 * 1024;  // dynamic LDS a kernel may ask for: 160 KiB less room for its static arrays
 
 template <typename T>
 static size_t line_bytes(int L) {
@@ -1148,6 +1322,151 @@ static int allow_lds(mistitch_ctx* ctx, KernelT kernel, size_t bytes) {
   return MISTITCH_OK;
 }
 
+// ---- strips with a side that is not a power of two ----------------------------
+struct GenShape {
+  int S, L;
+  GenPlanDev ps, pl;  // short axis, long axis
+  int C;              // columns per k_gen_cols block
+  size_t lds_rows, lds_cols;
+};
+
+// In-place radix-2 FFT in long double (host, plan construction only).
+static void host_fft(std::vector<long double>& re, std::vector<long double>& im) {
+  const size_t n = re.size();
+  for (size_t i = 1, j = 0; i < n; ++i) {
+    size_t bit = n >> 1;
+    for (; j & bit; bit >>= 1) j ^= bit;
+    j ^= bit;
+    if (i < j) {
+      std::swap(re[i], re[j]);
+      std::swap(im[i], im[j]);
+    }
+  }
+  const long double pi = 3.14159265358979323846264338327950288L;
+  for (size_t len = 2; len <= n; len <<= 1) {
+    for (size_t k = 0; k < len / 2; ++k) {
+      const long double ang = -2.0L * pi * (long double)k / (long double)len;
+      const long double wr = cosl(ang), wi = sinl(ang);
+      for (size_t i = k; i < n; i += len) {
+        const size_t j = i + len / 2;
+        const long double tr = re[j] * wr - im[j] * wi, ti = re[j] * wi + im[j] * wr;
+        re[j] = re[i] - tr;
+        im[j] = im[i] - ti;
+        re[i] += tr;
+        im[i] += ti;
+      }
+    }
+  }
+}
+
+static int build_gen_plan(mistitch_ctx* ctx, int n, GenPlanDev* out) {
+  auto it = ctx->gen_plans.find(n);
+  if (it != ctx->gen_plans.end()) {
+    memcpy(out, it->second.data(), sizeof(GenPlanDev));
+    return MISTITCH_OK;
+  }
+  int M = 16;
+  while (M < 2 * n - 1) M <<= 1;
+  MS_REQUIRE(M <= 8192, MISTITCH_ERR_UNSUPPORTED, "side %d too long for the chirp-z path (at most 4096)", n);
+  GenPlanDev gp;
+  gp.n = n;
+  gp.M = M;
+  int rc = build_plan(ctx, M, true, &gp.planM);
+  if (rc) return rc;
+  const long double pi = 3.14159265358979323846264338327950288L;
+  std::vector<double> chirp(2 * (size_t)n);
+  std::vector<long double> bre(M, 0.0L), bim(M, 0.0L);
+  for (int j = 0; j < n; ++j) {
+    const long long r = ((long long)j * j) % (2LL * n);  // exp(-i pi j^2 / n) has period 2n in j^2
+    const long double ang = -pi * (long double)r / (long double)n;
+    const long double c = cosl(ang), sn = sinl(ang);
+    chirp[2 * j] = (double)c;
+    chirp[2 * j + 1] = (double)sn;
+    bre[j] = c;
+    bim[j] = -sn;
+    if (j > 0) {
+      bre[M - j] = c;
+      bim[M - j] = -sn;
+    }
+  }
+  host_fft(bre, bim);
+  std::vector<uint16_t> pos2freq(M);
+  MS_HIP(hipMemcpy(pos2freq.data(), gp.planM.pos2freq, (size_t)M * 2, hipMemcpyDeviceToHost));
+  std::vector<double> bhat(2 * (size_t)M);
+  for (int pos = 0; pos < M; ++pos) {
+    bhat[2 * pos] = (double)(bre[pos2freq[pos]] / (long double)M);
+    bhat[2 * pos + 1] = (double)(bim[pos2freq[pos]] / (long double)M);
+  }
+  void* blob = nullptr;
+  const size_t cb = chirp.size() * sizeof(double), bb = bhat.size() * sizeof(double);
+  MS_HIP(hipMalloc(&blob, cb + bb));
+  ctx->shape_allocs.push_back(blob);
+  MS_HIP(hipMemcpy(blob, chirp.data(), cb, hipMemcpyHostToDevice));
+  MS_HIP(hipMemcpy(reinterpret_cast<char*>(blob) + cb, bhat.data(), bb, hipMemcpyHostToDevice));
+  gp.chirp = reinterpret_cast<const double2*>(blob);
+  gp.bhat = reinterpret_cast<const double2*>(reinterpret_cast<char*>(blob) + cb);
+  std::vector<char> rec(sizeof(GenPlanDev));
+  memcpy(rec.data(), &gp, sizeof(GenPlanDev));
+  ctx->gen_plans[n] = rec;
+  *out = gp;
+  return MISTITCH_OK;
+}
+
+static int make_gen_shape(mistitch_ctx* ctx, int S, int L, GenShape* g) {
+  MS_REQUIRE(S >= 1 && L >= 1 && S <= 4096 && L <= 4096, MISTITCH_ERR_UNSUPPORTED,
+             "strip %d x %d unsupported: sides must be within [1, 4096]", S, L);
+  g->S = S;
+  g->L = L;
+  int rc;
+  if ((rc = build_gen_plan(ctx, S, &g->ps))) return rc;
+  if ((rc = build_gen_plan(ctx, L, &g->pl))) return rc;
+  const size_t line_s = line_bytes<double>(g->ps.M), line_l = line_bytes<double>(g->pl.M);
+  const size_t tw_s = (size_t)Twiddles<double>::entries(g->ps.M) * 16, tw_l = (size_t)Twiddles<double>::entries(g->pl.M) * 16;
+  g->lds_rows = line_l + tw_l;
+  int C = (int)((kLdsBudget - tw_s) / line_s);
+  if (C < 1) C = 1;
+  if (C > 8) C = 8;
+  g->C = C;
+  g->lds_cols = line_s * C + tw_s;
+  MS_REQUIRE(g->lds_rows <= kLdsMax && g->lds_cols <= kLdsMax, MISTITCH_ERR_UNSUPPORTED,
+             "strip %d x %d needs more LDS than a workgroup has", S, L);
+  return MISTITCH_OK;
+}
+
+// Either decomposition of one canonical strip shape, and what it needs from the workspace.
+struct AnyShape {
+  bool general;
+  ShapeCfg fast;
+  GenShape gen;
+  int S, L;
+  int nblk;           // blocks of the last pass = partial peak lists per pair
+  size_t spec_bytes;  // per pair, in RegWorkspace::spectrum
+  size_t slab_bytes;  // per pair, in RegWorkspace::slabs
+};
+
+static bool fast_shape_ok(int S, int L) {
+  return is_pow2(S) && is_pow2(L) && S >= 8 && L >= 8 && L <= 4096 && S <= 1024;
+}
+
+static int make_any_shape(mistitch_ctx* ctx, int S, int L, bool f64, AnyShape* a) {
+  a->S = S;
+  a->L = L;
+  a->general = !fast_shape_ok(S, L);
+  int rc;
+  if (a->general) {
+    if ((rc = make_gen_shape(ctx, S, L, &a->gen))) return rc;
+    a->nblk = S;
+    a->spec_bytes = a->slab_bytes = (size_t)S * L * 16;
+  } else {
+    if ((rc = make_shape(ctx, S, L, f64, &a->fast))) return rc;
+    const size_t esz = f64 ? 16 : 8;
+    a->nblk = S / (2 * a->fast.NF_inv);
+    a->spec_bytes = (size_t)S * (L + 128 / esz) * esz;
+    a->slab_bytes = (size_t)slab_pair_elems(S, L) * esz;
+  }
+  return MISTITCH_OK;
+}
+
 struct RegWorkspace {
   PairDesc* desc;
   uint16_t* staging;
@@ -1213,6 +1532,39 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
   return MISTITCH_OK;
 }
 
+// The chirp-z pipeline for pairs [pair0, pair0 + n) of one canonical shape.
+static int launch_fft_general(mistitch_ctx* ctx, const GenShape& g, const RegWorkspace& ws, const int8_t* status,
+                              int pair0, int n, int want_transposed, int k, double* pcm_out) {
+  double2* Zf = reinterpret_cast<double2*>(ws.slabs);
+  double2* R = reinterpret_cast<double2*>(ws.spectrum);
+  int rc;
+  if ((rc = allow_lds(ctx, k_gen_rows_fwd, g.lds_rows))) return rc;
+  if ((rc = allow_lds(ctx, k_gen_cols, g.lds_cols))) return rc;
+  if ((rc = allow_lds(ctx, k_gen_rows_inv, g.lds_rows))) return rc;
+  const double eps = std::numeric_limits<double>::epsilon() * 100.0;
+  const int col_blocks = (g.L + g.C - 1) / g.C;
+  MS_LAUNCH(ctx, "k_gen_rows_fwd", k_gen_rows_fwd, dim3(g.S, n), dim3(kThreads), g.lds_rows, ws.desc, status, pair0, g.S, g.L,
+            want_transposed, g.pl, Zf);
+  MS_LAUNCH(ctx, "k_gen_cols", k_gen_cols, dim3(col_blocks, n), dim3(kThreads), g.lds_cols, ws.desc, status, pair0, g.S, g.L,
+            want_transposed, g.ps, g.C, 0, Zf);
+  const int cps_blocks = std::max(1, std::min(1024, (g.S * g.L + kThreads - 1) / kThreads));
+  MS_LAUNCH(ctx, "k_gen_cps", k_gen_cps, dim3(cps_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, g.S, g.L,
+            want_transposed, Zf, R, eps);
+  MS_LAUNCH(ctx, "k_gen_cols", k_gen_cols, dim3(col_blocks, n), dim3(kThreads), g.lds_cols, ws.desc, status, pair0, g.S, g.L,
+            want_transposed, g.ps, g.C, 1, R);
+  MS_LAUNCH(ctx, "k_gen_rows_inv", k_gen_rows_inv, dim3(g.S, n), dim3(kThreads), g.lds_rows, ws.desc, status, pair0, g.S, g.L,
+            want_transposed, g.pl, R, k, ws.partial, ws.partial_stride, pcm_out);
+  MS_HIP(hipGetLastError());
+  return MISTITCH_OK;
+}
+
+static int launch_any(mistitch_ctx* ctx, const AnyShape& a, bool f64, const RegWorkspace& ws, const int8_t* status,
+                      int pair0, int n, int want_transposed, bool vec_ok, int k, double* pcm_out) {
+  if (a.general) return launch_fft_general(ctx, a.gen, ws, status, pair0, n, want_transposed, k, pcm_out);
+  return f64 ? launch_fft<double>(ctx, a.fast, ws, status, pair0, n, want_transposed, vec_ok, k, pcm_out)
+             : launch_fft<float>(ctx, a.fast, ws, status, pair0, n, want_transposed, vec_ok, k, pcm_out);
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 }  // namespace mistitch
@@ -1233,16 +1585,15 @@ extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int 
   const bool f64 = !(flags & MISTITCH_FFT_F32);
   const int w_left = edge_width < tile_w ? edge_width : tile_w;
   const int w_top = edge_width < tile_h ? edge_width : tile_h;
-  ShapeCfg a, b;
+  AnyShape a, b;
   int rc;
-  if ((rc = make_shape(ctx, w_left, tile_h, f64, &a))) return rc;
-  if ((rc = make_shape(ctx, w_top, tile_w, f64, &b))) return rc;
-  const size_t esz = f64 ? 16 : 8;
-  const size_t spec = std::max((size_t)a.S * (a.L + 128 / esz), (size_t)b.S * (b.L + 128 / esz)) * esz;
-  const int pstride = std::max(a.S / (2 * a.NF_inv), b.S / (2 * b.NF_inv)) * kMaxK;
+  if ((rc = make_any_shape(ctx, w_left, tile_h, f64, &a))) return rc;
+  if ((rc = make_any_shape(ctx, w_top, tile_w, f64, &b))) return rc;
+  const size_t spec = std::max(a.spec_bytes, b.spec_bytes);
+  const int pstride = std::max(a.nblk, b.nblk) * kMaxK;
   const int chunk = max_pairs < ctx->pair_chunk ? max_pairs : ctx->pair_chunk;
   RegWorkspace ws;
-  const size_t slab = (size_t)std::max(slab_pair_elems(a.S, a.L), slab_pair_elems(b.S, b.L)) * esz;
+  const size_t slab = std::max(a.slab_bytes, b.slab_bytes);
   return reserve_registration(ctx, max_pairs, chunk, (size_t)w_left * tile_h * 2, spec, slab, pstride, &ws);
 }
 
@@ -1261,19 +1612,16 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
   const int H = tile_h, W = tile_w;
   const int w_left = edge_width < W ? edge_width : W;
   const int w_top = edge_width < H ? edge_width : H;
-  ShapeCfg cfg_left, cfg_top;
+  AnyShape cfg_left, cfg_top;
   int rc;
-  if ((rc = make_shape(ctx, w_left, H, f64, &cfg_left))) return rc;
-  if ((rc = make_shape(ctx, w_top, W, f64, &cfg_top))) return rc;
+  if ((rc = make_any_shape(ctx, w_left, H, f64, &cfg_left))) return rc;
+  if ((rc = make_any_shape(ctx, w_top, W, f64, &cfg_top))) return rc;
   const bool same_shape = cfg_left.S == cfg_top.S && cfg_left.L == cfg_top.L;
-  const size_t esz = f64 ? 16 : 8;
-  const size_t spec =
-      std::max((size_t)cfg_left.S * (cfg_left.L + 128 / esz), (size_t)cfg_top.S * (cfg_top.L + 128 / esz)) * esz;
-  const int pstride = std::max(cfg_left.S / (2 * cfg_left.NF_inv), cfg_top.S / (2 * cfg_top.NF_inv)) * kMaxK;
+  const size_t spec = std::max(cfg_left.spec_bytes, cfg_top.spec_bytes);
+  const int pstride = std::max(cfg_left.nblk, cfg_top.nblk) * kMaxK;
   const int chunk = n_pairs < ctx->pair_chunk ? n_pairs : ctx->pair_chunk;
   RegWorkspace ws;
-  const size_t slab =
-      (size_t)std::max(slab_pair_elems(cfg_left.S, cfg_left.L), slab_pair_elems(cfg_top.S, cfg_top.L)) * esz;
+  const size_t slab = std::max(cfg_left.slab_bytes, cfg_top.slab_bytes);
   if ((rc = reserve_registration(ctx, n_pairs, chunk, (size_t)w_left * H * 2, spec, slab, pstride, &ws))) return rc;
   // 16-byte loads of tile rows need aligned rows; staging lines always are.
   const bool vec_top = aligned16(tiles) && (W % 8 == 0) && (tile_pitch % 8 == 0);
@@ -1293,20 +1641,13 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
                 tiles, tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
     if (same_shape) {
       // left strips come from the aligned staging buffer, top strips from the tiles
-      rc = f64 ? launch_fft<double>(ctx, cfg_left, ws, status, pair0, n, -1, vec_top, k, nullptr)
-               : launch_fft<float>(ctx, cfg_left, ws, status, pair0, n, -1, vec_top, k, nullptr);
-      if (rc) return rc;
+      if ((rc = launch_any(ctx, cfg_left, f64, ws, status, pair0, n, -1, vec_top, k, nullptr))) return rc;
     } else {
-      rc = f64 ? launch_fft<double>(ctx, cfg_left, ws, status, pair0, n, 1, true, k, nullptr)
-               : launch_fft<float>(ctx, cfg_left, ws, status, pair0, n, 1, true, k, nullptr);
-      if (rc) return rc;
-      rc = f64 ? launch_fft<double>(ctx, cfg_top, ws, status, pair0, n, 0, vec_top, k, nullptr)
-               : launch_fft<float>(ctx, cfg_top, ws, status, pair0, n, 0, vec_top, k, nullptr);
-      if (rc) return rc;
+      if ((rc = launch_any(ctx, cfg_left, f64, ws, status, pair0, n, 1, true, k, nullptr))) return rc;
+      if ((rc = launch_any(ctx, cfg_top, f64, ws, status, pair0, n, 0, vec_top, k, nullptr))) return rc;
     }
     MS_LAUNCH(ctx, "k_peaks_candidates", k_peaks_candidates, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, ws.partial,
-                       ws.partial_stride, cfg_top.S / (2 * cfg_top.NF_inv), cfg_left.S / (2 * cfg_left.NF_inv), k, 2,
-                       ws.peaks, ws.cand, ws.acc);
+                       ws.partial_stride, cfg_top.nblk, cfg_left.nblk, k, 2, ws.peaks, ws.cand, ws.acc);
     MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(kNccChunks, kNumCand, n), dim3(kThreads), 0, ws.desc, status, pair0,
                        ws.cand, ws.acc);
   }
@@ -1328,15 +1669,12 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   const bool f64 = !(flags & MISTITCH_FFT_F32);
   const bool transposed = h > w;  // tall strips are processed transposed
   const int S = transposed ? w : h, L = transposed ? h : w;
-  ShapeCfg cfg;
+  AnyShape cfg;
   int rc;
-  if ((rc = make_shape(ctx, S, L, f64, &cfg))) return rc;
-  const size_t esz = f64 ? 16 : 8;
-  const int pstride = (cfg.S / (2 * cfg.NF_inv)) * kMaxK;
+  if ((rc = make_any_shape(ctx, S, L, f64, &cfg))) return rc;
+  const int pstride = cfg.nblk * kMaxK;
   RegWorkspace ws;
-  if ((rc = reserve_registration(ctx, 1, 1, (size_t)S * L, (size_t)S * (L + 128 / esz) * esz,
-                                 (size_t)slab_pair_elems(S, L) * esz, pstride, &ws)))
-    return rc;
+  if ((rc = reserve_registration(ctx, 1, 1, (size_t)S * L, cfg.spec_bytes, cfg.slab_bytes, pstride, &ws))) return rc;
   if ((rc = ctx->misc.reserve(256))) return rc;
   hipStream_t st = ctx->stream;
   PairDesc d;
@@ -1375,12 +1713,10 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   MS_HIP(hipMemsetAsync(status, 0, 16, st));
   MS_HIP(hipMemcpyAsync(ws.desc, &d, sizeof(d), hipMemcpyHostToDevice, st));
   MS_HIP(hipStreamSynchronize(st));  // d lives on this stack frame
-  rc = f64 ? launch_fft<double>(ctx, cfg, ws, status, 0, 1, -1, vec, k, out_pcm)
-           : launch_fft<float>(ctx, cfg, ws, status, 0, 1, -1, vec, k, out_pcm);
-  if (rc) return rc;
+  if ((rc = launch_any(ctx, cfg, f64, ws, status, 0, 1, -1, vec, k, out_pcm))) return rc;
   if (k > 0) {
     MS_LAUNCH(ctx, "k_peaks_candidates", k_peaks_candidates, dim3(1), dim3(kThreads), 0, ws.desc, status, 0, ws.partial,
-                       ws.partial_stride, cfg.S / (2 * cfg.NF_inv), cfg.S / (2 * cfg.NF_inv), k, 0, ws.peaks,
+                       ws.partial_stride, cfg.nblk, cfg.nblk, k, 0, ws.peaks,
                        (Cand*)nullptr, (unsigned long long*)nullptr);
     MS_LAUNCH(ctx, "k_peaks_to_arrays", k_peaks_to_arrays, dim3(1), dim3(64), 0, ws.peaks, k, w, rows, cols, vals);
   }

@@ -64,7 +64,7 @@ int mistitch_create(int device, void* stream, mistitch_ctx** out);
 int mistitch_destroy(mistitch_ctx* ctx);
 
 /* Pairs are processed in passes of `pairs_per_pass` (>=1) to bound the FFT
- * workspace (about 10.5 MB per pair at edge width 256 with complex128 spectra).
+ * workspace (about 19 MB per pair at edge width 256 with complex128 spectra).
  * Default 128. */
 int mistitch_set_pair_chunk(mistitch_ctx* ctx, int pairs_per_pass);
 
@@ -88,7 +88,9 @@ int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int
  *              the first tile's frame; NaN row when status is FEATURELESS
  *   status     [n_pairs] int8: MISTITCH_PAIR_*
  *
- * Strip sides must be powers of two within [8, 4096] (long) / [8, 1024] (short).
+ * Strips whose sides are powers of two (long side 8..4096, short side 8..1024)
+ * take the Hermitian radix-16 path; any other side lengths up to 4096 take
+ * chirp-z transforms (complex128 whatever `flags` says, several times slower).
  */
 int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h,
                             int tile_w, int64_t tile_pitch, const int32_t* pair_idx,

@@ -21,20 +21,11 @@ def _grid(spec):
                            overlap=spec["overlap"], jitter=spec["jitter"])
 
 
-def _pow2(n):
-    return n & (n - 1) == 0
-
-
-def _supported(spec):
-    return all(_pow2(v) for v in (spec["tile_h"], spec["tile_w"], min(spec["edge_width"], spec["tile_h"]),
-                                  min(spec["edge_width"], spec["tile_w"])))
-
-
 @pytest.mark.parametrize("fft", ["f64", "f32"])
 def test_grids_match_reference_golden(reg, golden, fft):
+    """Every golden grid, the ones with sides that are not powers of two included
+    (edge width 195, 300x420 tiles): those run the chirp-z transforms."""
     for spec in golden["grids"]:
-        if not _supported(spec):
-            continue
         g = _grid(spec)
         out, status = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, spec["edge_width"], fft=fft)
         out, status = out.cpu().numpy(), status.cpu().numpy()
@@ -46,11 +37,31 @@ def test_grids_match_reference_golden(reg, golden, fft):
         assert np.array_equal(out[:, 1:].astype(np.int64), g.expected_shift)
 
 
-def test_unsupported_shape_is_an_error(reg, golden):
-    spec = [s for s in golden["grids"] if not _supported(s)][0]
-    g = _grid(spec)
+def test_unsupported_shape_is_an_error(reg):
+    """Sides beyond 4096 are refused with an error, never computed wrongly."""
+    tiles = np.zeros((2, 16, 4100), dtype=np.uint16)
     with pytest.raises(Exception):
-        reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, spec["edge_width"])
+        reg.register_pairs(tiles, [[0, 1]], [1], 16)
+
+
+@pytest.mark.parametrize("shape", [(50, 300), (195, 512), (97, 101), (64, 300), (30, 1000), (7, 9), (130, 64)])
+def test_pcm_of_any_size(reg, shape):
+    """PCM and its ranking for strips whose sides are not powers of two (primes, odd, tall)."""
+    h, w = shape
+    big = synth.make_scene(900 + h + w, h + 16, w + 16)
+    a = np.ascontiguousarray(big[8:8 + h, 8:8 + w])
+    b = np.ascontiguousarray(big[8 + 2:8 + 2 + h, 8 - 3:8 - 3 + w])
+    ref = oreg.pcm(a, b)
+    got = reg.pcm(a, b)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 1e-11
+    k = 4
+    rows, cols, vals = reg.pcm_topk(a, b, k)
+    er, ec, ev = oreg.multi_peak_max(ref)
+    for i in range(k):
+        assert vals[i] == pytest.approx(ev[i], abs=1e-11)
+        if i + 1 < len(ev) and abs(ev[i] - ev[i + 1]) > 1e-9 and (i == 0 or abs(ev[i - 1] - ev[i]) > 1e-9):
+            assert (rows[i], cols[i]) == (er[i], ec[i])
 
 
 def test_matches_oracle_on_fresh_seeds(reg):
