@@ -21,6 +21,7 @@ OK = 0
 ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM = -1, -2, -3, -4
 PAIR_OK, PAIR_FEATURELESS, PAIR_NO_CANDIDATE = 0, 1, 2
 FFT_F64, FFT_F32 = 0, 1
+REG_SUBPIXEL = 2
 FUSE_OVERWRITE, FUSE_FEATHER = 0, 1
 FF_NONE, FF_F32, FF_F64 = 0, 1, 2
 
@@ -29,7 +30,8 @@ EXPORTS = [
     "mistitch_set_pair_chunk", "mistitch_reserve_registration", "mistitch_register_pairs",
     "mistitch_pcm", "mistitch_pcm_topk", "mistitch_ncc", "mistitch_edge_variance",
     "mistitch_apply_flatfield", "mistitch_fuse", "mistitch_mip", "mistitch_synchronize",
-    "mistitch_profile_enable", "mistitch_profile_collect",
+    "mistitch_profile_enable", "mistitch_profile_collect", "mistitch_subpixel_shift",
+    "mistitch_set_upsample_factor",
 ]
 
 
@@ -57,6 +59,8 @@ def _load() -> C.CDLL:
         "mistitch_pcm": [vp, vp, i64, vp, i64, i32, i32, u32, vp],
         "mistitch_pcm_topk": [vp, vp, i64, vp, i64, i32, i32, u32, i32, vp, vp, vp],
         "mistitch_ncc": [vp, vp, i64, vp, i64, i32, i32, vp],
+        "mistitch_subpixel_shift": [vp, vp, i64, vp, i64, i32, i32, u32, i32, vp],
+        "mistitch_set_upsample_factor": [vp, i32],
         "mistitch_edge_variance": [vp, vp, i64, i32, i32, vp],
         "mistitch_apply_flatfield": [vp, vp, vp, i32, vp, i32, i32, i32],
         "mistitch_fuse": [vp, vp, i32, i32, i32, i64, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32],
@@ -109,6 +113,9 @@ class Context:
 
     def set_pair_chunk(self, n: int) -> None:
         check(lib.mistitch_set_pair_chunk(self.handle, int(n)))
+
+    def set_upsample_factor(self, u: int) -> None:
+        check(lib.mistitch_set_upsample_factor(self.handle, int(u)))
 
     def synchronize(self) -> None:
         check(lib.mistitch_synchronize(self.handle))

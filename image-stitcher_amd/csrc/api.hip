@@ -28,7 +28,7 @@ extern "C" int mistitch_destroy(mistitch_ctx* ctx) {
   for (auto& kv : ctx->plans)
     if (kv.second.blob) (void)hipFree(kv.second.blob);
   DevBuf* bufs[] = {&ctx->desc,  &ctx->staging, &ctx->spectrum, &ctx->slabs, &ctx->partial,
-                    &ctx->peaks, &ctx->cand,    &ctx->acc,      &ctx->misc,  &ctx->bins,    &ctx->flags};
+                    &ctx->peaks, &ctx->cand,    &ctx->acc,      &ctx->misc,  &ctx->bins,    &ctx->flags,   &ctx->ups};
   for (DevBuf* b : bufs) b->release();
   for (void* q : ctx->shape_allocs) (void)hipFree(q);
   ctx->prof.destroy();

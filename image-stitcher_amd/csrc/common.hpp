@@ -150,8 +150,9 @@ struct mistitch_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   int pair_chunk = 128;  // pairs processed per pipeline pass (bounds the FFT workspace)
+  int upsample_factor = 100;  // subpixel grid: 1 / upsample_factor pixels
   std::map<long long, mistitch::FftPlanHost> plans;  // key = n * 2 + (is_f64)
-  mistitch::DevBuf desc, staging, spectrum, slabs, partial, peaks, cand, acc, misc, bins, flags;
+  mistitch::DevBuf desc, staging, spectrum, slabs, partial, peaks, cand, acc, misc, bins, flags, ups;
   std::vector<char> host_scratch;
   std::set<const void*> lds_enabled;  // kernels already granted large dynamic LDS
   std::map<long long, std::vector<char>> shapes;  // cached per-strip-shape launch configuration

@@ -46,6 +46,9 @@ constexpr int kThreads = 256;
 constexpr int kMaxK = 16;       // peaks a block / a pair can report
 constexpr int kNumCand = 32;    // 2 peaks x 16 signed interpretations
 constexpr int kNccChunks = 32;  // workgroups cooperating on one candidate
+constexpr int kCandSlots = kNumCand + 1;  // the last slot holds the subpixel estimate's rounded shift (flag 1 when unused)
+constexpr int kUpsMax = 160;    // largest upsampled region side (ceil(1.5 * upsample factor))
+constexpr int kUpsRows = 10;    // upsampled rows per block of the second stage
 
 struct PairDesc {
   const uint16_t* a;  // canonical strip of the first tile
@@ -61,6 +64,14 @@ struct Peak {
   double val;
   int key;  // flat index in image orientation; -1 = none
   int loc;  // block-local location (selection bookkeeping)
+};
+
+// Subpixel refinement state of a pair (all along the canonical axes).
+struct UpsState {
+  int shift_s, shift_l;  // coarse shift: signed position of the largest |PCM| value
+  int valid;             // 0: no usable coarse peak
+  int pad;
+  double sub_s, sub_l;   // refined shift
 };
 
 struct Cand {
@@ -113,6 +124,36 @@ __device__ __forceinline__ Peak block_argmax(Peak mine, Peak* red /*[kThreads/64
   for (int w = 1; w < kThreads / 64; ++w) {
     Peak o = red[w];
     if (peak_better(o.val, o.key, best.val, best.key)) best = o;
+  }
+  return best;
+}
+
+// Block-wide argmax where the SMALLEST key wins among equal values (the first
+// occurrence in row-major order, as numpy.argmax reports); result valid in every thread.
+__device__ __forceinline__ bool first_better(double v, int k, double bv, int bk) {
+  return (v > bv) || (v == bv && k >= 0 && (bk < 0 || k < bk));
+}
+__device__ __forceinline__ Peak block_argmax_first(Peak mine, Peak* red /*[kThreads/64]*/) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    double ov = __shfl_xor(mine.val, off);
+    int ok = __shfl_xor(mine.key, off);
+    int ol = __shfl_xor(mine.loc, off);
+    if (first_better(ov, ok, mine.val, mine.key)) {
+      mine.val = ov;
+      mine.key = ok;
+      mine.loc = ol;
+    }
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wave] = mine;
+  __syncthreads();
+  Peak best = red[0];
+#pragma unroll
+  for (int w = 1; w < kThreads / 64; ++w) {
+    Peak o = red[w];
+    if (first_better(o.val, o.key, best.val, best.key)) best = o;
   }
   return best;
 }
@@ -400,7 +441,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
                                                             int pair0, int S, int L, int want_transposed,
                                                             FftPlanDev planS, FftPlanDev planL,
                                                             const CpsUnit* __restrict__ units, int rs,
-                                                            const cx<T>* __restrict__ slabs, cx<T>* spectrum, T eps) {
+                                                            const cx<T>* slabs, cx<T>* spectrum, T eps,
+                                                            cx<T>* keep_r) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
   const int p = pair0 + blockIdx.y;
@@ -472,6 +514,16 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   }
   __syncthreads();
   MS_STAMP(1, 3);
+  if (keep_r != nullptr) {
+    // the subpixel stage wants the normalised spectrum itself: it replaces this unit's own
+    // columns of the slab buffer, which no other workgroup reads
+    cx<T>* Rs = keep_r + (int64_t)blockIdx.y * slab_pair_elems(S, L);
+    for (int e = tid; e < S * na; e += kThreads) {
+      const int q = e / na, c = e - q * na;
+      const int pos = un.a0 + c;
+      Rs[(pos / kSlab) * sp + q * kSlab + pos % kSlab] = buf[q * rs + c];
+    }
+  }
   fft_inverse<T>(buf, addr, na, planS, tw, tid, kThreads);
   MS_STAMP(1, 4);
   for (int e = tid; e < S * na; e += kThreads) {
@@ -489,7 +541,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
                                                            FftPlanDev planL, const uint16_t* __restrict__ stored_pos,
                                                            const uint16_t* __restrict__ mirror_fill, int n_stored,
                                                            int NF, const cx<T>* spectrum, int k, Peak* partial,
-                                                           int partial_stride, double* pcm_out) {
+                                                           int partial_stride, double* pcm_out, Peak* partial_abs,
+                                                           int abs_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
   __shared__ Peak red[kThreads / 64];
@@ -562,6 +615,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
     // The production case: one scan keeps each lane's two best values, then k argmax
     // rounds in which a lane whose best was taken offers its second best.
     Peak b1{-INFINITY, -1, -1}, b2{-INFINITY, -1, -1};
+    Peak ba{-INFINITY, -1, -1};  // largest magnitude, first in row-major order (subpixel stage only)
     for (int e = tid; e < NF * L; e += kThreads) {
       const int f = e / L, l = e - f * L;
       const int a0 = addr(f, l);
@@ -582,6 +636,15 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       } else if (peak_better(c1.val, c1.key, b2.val, b2.key)) {
         b2 = c1;
       }
+      if (partial_abs != nullptr) {
+        if (first_better(fabs(c0.val), c0.key, ba.val, ba.key)) ba = Peak{fabs(c0.val), c0.key, 0};
+        if (first_better(fabs(c1.val), c1.key, ba.val, ba.key)) ba = Peak{fabs(c1.val), c1.key, 0};
+      }
+    }
+    if (partial_abs != nullptr) {
+      const Peak best = block_argmax_first(ba, red);
+      if (tid == 0) partial_abs[(int64_t)blockIdx.y * abs_stride + blockIdx.x] = best;
+      __syncthreads();
     }
     for (int round = 0; round < k; ++round) {
       const Peak best = block_argmax(b1, red);
@@ -798,8 +861,8 @@ __global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* d
                                                                int pair0, Peak* partial, int partial_stride,
                                                                int nblk_direct, int nblk_transposed, int k,
                                                                int n_peaks_used, Peak* peaks /*[P][kMaxK]*/,
-                                                               Cand* cand /*[P][kNumCand]*/,
-                                                               unsigned long long* acc /*[P][kNumCand][5]*/) {
+                                                               Cand* cand /*[P][kCandSlots]*/,
+                                                               unsigned long long* acc /*[P][kCandSlots][5]*/) {
   __shared__ Peak red[kThreads / 64];
   __shared__ Peak top[kMaxK];
   const int p = pair0 + blockIdx.x;
@@ -823,6 +886,10 @@ __global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* d
     __syncthreads();
   }
   if (cand == nullptr) return;
+  if (tid == kNumCand) {  // the subpixel slot stays unused until k_ups_finish fills it
+    cand[(int64_t)p * kCandSlots + kNumCand] = Cand{0, 0, 1, -1};
+    for (int i = 0; i < 5; ++i) acc[((int64_t)p * kCandSlots + kNumCand) * 5 + i] = 0ull;
+  }
   __shared__ Cand sc[kNumCand];
   if (tid < kNumCand) {
     const int pk = tid >> 4, t = tid & 15;
@@ -843,7 +910,7 @@ __global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* d
       }
     }
     sc[tid] = c;
-    for (int i = 0; i < 5; ++i) acc[((int64_t)p * kNumCand + tid) * 5 + i] = 0ull;
+    for (int i = 0; i < 5; ++i) acc[((int64_t)p * kCandSlots + tid) * 5 + i] = 0ull;
   }
   __syncthreads();
   if (tid < kNumCand) {
@@ -858,8 +925,268 @@ __global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* d
         }
       }
     }
-    cand[(int64_t)p * kNumCand + tid] = c;
+    cand[(int64_t)p * kCandSlots + tid] = c;
   }
+}
+
+// ---------------------------------------------------------------------------
+// Subpixel refinement by upsampled DFT (the matrix-multiply refinement of
+// Guizar-Sicairos, Thurman and Fienup, as skimage.registration.phase_cross_correlation
+// runs it for registration/_translation_computation.py:1233-1272): the inverse DFT of
+// the normalised cross-power spectrum R is re-evaluated on an n_up x n_up grid of
+// spacing 1/u around the coarse peak,
+//   CC(ds, dl) = sum_{a,b} R[a,b] exp(2 pi i (ds ks(a) / S + dl kl(b) / L)),
+// ks, kl the signed frequencies (Nyquist counted negative, as numpy.fft.fftfreq does).
+// Only one column b of every conjugate pair {b, -b} is stored.  With
+//   X_b(ds) = sum_a R[a,b] exp(2 pi i ds ks(a) / S)          (first stage, k_ups_short)
+// the pair contributes 2 Re(X_b e_b) + c_b conj(e_b), e_b = exp(2 pi i dl kl(b) / L),
+// where c_b = -2i sin(pi ds) conj(R[S/2, b]) accounts for the Nyquist row, whose signed
+// frequency is not negated by conjugation; self-conjugate columns contribute X_b e_b
+// (second stage, k_ups_long).
+// Coarse shift of the subpixel stage: the pair's largest |PCM| value (first in row-major
+// order on ties), wrapped to signed about the midpoint.  grid (pairs_in_pass).
+__global__ __launch_bounds__(kThreads) void k_ups_coarse(const PairDesc* desc, const int8_t* status, int pair0, int S,
+                                                         int L, int want_transposed, const Peak* partial_abs,
+                                                         int abs_stride, int nblk, UpsState* ups) {
+  __shared__ Peak red[kThreads / 64];
+  const int p = pair0 + blockIdx.x;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  Peak mine{-INFINITY, -1, -1};
+  for (int e = threadIdx.x; e < nblk; e += kThreads) {
+    const Peak c = partial_abs[(int64_t)blockIdx.x * abs_stride + e];
+    if (first_better(c.val, c.key, mine.val, mine.key)) mine = c;
+  }
+  const Peak best = block_argmax_first(mine, red);
+  if (threadIdx.x == 0) {
+    UpsState u{0, 0, 0, 0, 0.0, 0.0};
+    if (best.key >= 0) {
+      int sy = best.key / d.img_w, sx = best.key - sy * d.img_w;
+      if (sy > d.img_h / 2) sy -= d.img_h;
+      if (sx > d.img_w / 2) sx -= d.img_w;
+      u.shift_s = d.transposed ? sx : sy;
+      u.shift_l = d.transposed ? sy : sx;
+      u.valid = 1;
+    }
+    ups[p] = u;
+  }
+}
+
+struct KappaEntry {
+  uint16_t stored;  // index into the stored-position list of the column with |kl| = kappa
+  int8_t sign;      // +1: its signed frequency is +kappa, -1: -kappa
+  int8_t self;      // 1: the column is its own conjugate partner (kappa = 0 or L / 2)
+};
+
+// grid (n_units, pairs_in_pass); threads 0 .. n_up-1 own one displacement each.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, const int8_t* status, int pair0, int S,
+                                                        int L, int want_transposed, FftPlanDev planS,
+                                                        const CpsUnit* __restrict__ units,
+                                                        const uint16_t* __restrict__ pos2stored, int n_stored,
+                                                        const cx<T>* __restrict__ rslabs,
+                                                        const UpsState* __restrict__ ups, int n_up, double uf,
+                                                        double2* __restrict__ T1, double2* __restrict__ Nq) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cx<T>* tile = reinterpret_cast<cx<T>*>(smem_raw);
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  {
+    const PairDesc& d = desc[p];
+    if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  }
+  const UpsState st = ups[p];
+  if (!st.valid) return;
+  const CpsUnit un = units[blockIdx.x];
+  const int na = un.na, tid = threadIdx.x;
+  const cx<T>* Rs = rslabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
+  const int64_t sp = slab_pitch(S);
+  for (int e = tid; e < S * na; e += kThreads) {
+    const int q = e / na, c = e - q * na;
+    const int pos = un.a0 + c;
+    tile[e] = Rs[(pos / kSlab) * sp + q * kSlab + pos % kSlab];
+  }
+  __syncthreads();
+  double2* t1 = T1 + (int64_t)blockIdx.y * n_up * n_stored;
+  const int nyq = planS.freq2pos[S / 2];
+  if (tid < na) {
+    const cx<T> v = tile[nyq * na + tid];
+    Nq[(int64_t)blockIdx.y * n_stored + pos2stored[un.a0 + tid]] = mk<double>((double)v.x, (double)v.y);
+  }
+  if (tid >= n_up) return;
+  const double delta = (double)st.shift_s + ((double)tid - (double)(n_up / 2)) / uf;
+  const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
+  double sn, cs;
+  sincos(theta, &sn, &cs);
+  const double2 step = mk<double>(cs, sn);
+  sincos(theta * (double)(-(S / 2)), &sn, &cs);
+  double2 w = mk<double>(cs, sn);  // exp(i theta k), k = -S/2 first
+  constexpr int kMaxCols = 16;
+  double2 acc[kMaxCols];
+#pragma unroll
+  for (int c = 0; c < kMaxCols; ++c) acc[c] = mk<double>(0.0, 0.0);
+  for (int kk = 0; kk < S; ++kk) {
+    const int k = kk - S / 2;
+    const int pos_q = planS.freq2pos[(k + S) & (S - 1)];
+    const cx<T>* row = tile + pos_q * na;
+#pragma unroll
+    for (int c = 0; c < kMaxCols; ++c) {
+      if (c < na) {
+        const double rx = (double)row[c].x, ry = (double)row[c].y;
+        acc[c].x += rx * w.x - ry * w.y;
+        acc[c].y += rx * w.y + ry * w.x;
+      }
+    }
+    w = cmul(w, step);
+  }
+#pragma unroll
+  for (int c = 0; c < kMaxCols; ++c)
+    if (c < na) t1[(int64_t)tid * n_stored + pos2stored[un.a0 + c]] = acc[c];
+}
+
+// grid (ceil(n_up / kUpsRows), pairs_in_pass); thread ul owns one long-axis displacement
+// and kUpsRows short-axis ones.  Emits the block's largest |CC|^2, first in the
+// row-major order of the IMAGE orientation on ties.
+__global__ __launch_bounds__(kThreads) void k_ups_long(const PairDesc* desc, const int8_t* status, int pair0, int S, int L,
+                                                       int want_transposed, const KappaEntry* __restrict__ kappa,
+                                                       int n_stored, const double2* __restrict__ T1,
+                                                       const double2* __restrict__ Nq,
+                                                       const UpsState* __restrict__ ups, int n_up, double uf,
+                                                       Peak* partial_ups, int n_row_blocks) {
+  constexpr int kChunk = 64;
+  __shared__ double2 sY[kUpsRows][kChunk];  // stored column values, conjugated where the stored frequency is negative, times 2 unless self
+  __shared__ double2 sV[kChunk];            // Nyquist-row values, conjugated likewise
+  __shared__ int8_t sSign[kChunk], sSelf[kChunk];
+  __shared__ Peak red[kThreads / 64];
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  const UpsState st = ups[p];
+  if (!st.valid) return;
+  const int tid = threadIdx.x;
+  const int us0 = blockIdx.x * kUpsRows;
+  const int nrows = min(kUpsRows, n_up - us0);
+  const double2* t1 = T1 + (int64_t)blockIdx.y * n_up * n_stored;
+  const double2* nq = Nq + (int64_t)blockIdx.y * n_stored;
+  const int ul = tid;
+  const double delta_l = (double)st.shift_l + ((double)ul - (double)(n_up / 2)) / uf;
+  const double theta = 2.0 * 3.14159265358979323846 * delta_l / (double)L;
+  double sn, cs;
+  sincos(theta, &sn, &cs);
+  const double2 step = mk<double>(cs, sn);
+  double2 w = mk<double>(1.0, 0.0);  // exp(i theta kappa)
+  double re[kUpsRows], im[kUpsRows];
+#pragma unroll
+  for (int r = 0; r < kUpsRows; ++r) re[r] = im[r] = 0.0;
+  double2 g1 = mk<double>(0.0, 0.0), g2 = mk<double>(0.0, 0.0);
+  const int n_kappa = L / 2 + 1;
+  for (int k0 = 0; k0 < n_kappa; k0 += kChunk) {
+    const int nk = min(kChunk, n_kappa - k0);
+    __syncthreads();
+    for (int e = tid; e < nk * (kUpsRows + 1); e += kThreads) {
+      const int j = e % nk, r = e / nk;
+      const KappaEntry ke = kappa[k0 + j];
+      if (r < kUpsRows) {
+        double2 x = mk<double>(0.0, 0.0);
+        if (r < nrows) x = t1[(int64_t)(us0 + r) * n_stored + ke.stored];
+        if (ke.sign < 0) x.y = -x.y;
+        if (!ke.self) {
+          x.x *= 2.0;
+          x.y *= 2.0;
+        }
+        sY[r][j] = x;
+      } else {
+        double2 v = nq[ke.stored];
+        if (ke.sign < 0) v.y = -v.y;
+        sV[j] = v;
+        sSign[j] = ke.sign;
+        sSelf[j] = ke.self;
+      }
+    }
+    __syncthreads();
+    for (int j = 0; j < nk; ++j) {
+      if (!sSelf[j]) {
+#pragma unroll
+        for (int r = 0; r < kUpsRows; ++r) re[r] += sY[r][j].x * w.x - sY[r][j].y * w.y;
+        const double2 vw = cmul(sV[j], w);
+        if (sSign[j] < 0) {
+          g1.x += vw.x;
+          g1.y += vw.y;
+        } else {
+          g2.x += vw.x;
+          g2.y += vw.y;
+        }
+      } else {
+        // X e for a self-conjugate column: real part as above, imaginary part with the sign of the stored frequency
+        const double sgn = sSign[j] < 0 ? -1.0 : 1.0;
+#pragma unroll
+        for (int r = 0; r < kUpsRows; ++r) {
+          re[r] += sY[r][j].x * w.x - sY[r][j].y * w.y;
+          im[r] += sgn * (sY[r][j].x * w.y + sY[r][j].y * w.x);
+        }
+      }
+      w = cmul(w, step);
+    }
+  }
+  // Nyquist-row term: -2i sin(pi ds) (g1 + conj(g2))
+  const double gx = g1.x + g2.x, gy = g1.y - g2.y;
+  Peak mine{-INFINITY, -1, -1};
+  if (ul < n_up) {
+#pragma unroll
+    for (int r = 0; r < kUpsRows; ++r) {
+      if (r < nrows) {
+        const int us = us0 + r;
+        const double delta_s = (double)st.shift_s + ((double)us - (double)(n_up / 2)) / uf;
+        const double s2 = 2.0 * sinpi(delta_s);
+        const double cr = re[r] + s2 * gy, ci = im[r] - s2 * gx;
+        const double mag2 = cr * cr + ci * ci;
+        const int key = d.transposed ? ul * n_up + us : us * n_up + ul;
+        if (first_better(mag2, key, mine.val, mine.key)) mine = Peak{mag2, key, 0};
+      }
+    }
+  }
+  const Peak best = block_argmax_first(mine, red);
+  if (tid == 0) partial_ups[(int64_t)blockIdx.y * n_row_blocks + blockIdx.x] = best;
+}
+
+// One thread per pair: the refined shift and its rounded position as the last candidate slot.
+__global__ void k_ups_finish(const PairDesc* desc, const int8_t* status, int pair0, int n, const Peak* partial_ups,
+                             int n_row_blocks, int n_up, double uf, UpsState* ups, Cand* cand) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int p = pair0 + i;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  UpsState st = ups[p];
+  if (!st.valid) return;
+  const PairDesc d = desc[p];
+  Peak best{-INFINITY, -1, -1};
+  for (int b = 0; b < n_row_blocks; ++b) {
+    const Peak c = partial_ups[(int64_t)i * n_row_blocks + b];
+    if (first_better(c.val, c.key, best.val, best.key)) best = c;
+  }
+  if (best.key < 0) {
+    st.valid = 0;
+    ups[p] = st;
+    return;
+  }
+  const int uy = best.key / n_up, ux = best.key - uy * n_up;
+  const int shift_y = d.transposed ? st.shift_l : st.shift_s, shift_x = d.transposed ? st.shift_s : st.shift_l;
+  const double sy = (double)shift_y + ((double)uy - (double)(n_up / 2)) / uf;
+  const double sx = (double)shift_x + ((double)ux - (double)(n_up / 2)) / uf;
+  st.sub_s = d.transposed ? sx : sy;
+  st.sub_l = d.transposed ? sy : sx;
+  ups[p] = st;
+  Cand c{(int)rint(sy), (int)rint(sx), 1, -1};
+  const int ay = c.y < 0 ? -c.y : c.y, ax = c.x < 0 ? -c.x : c.x;
+  if (ay >= d.img_h || ax >= d.img_w)
+    c.flag = 1;
+  else if ((long long)(d.img_h - ay) * (d.img_w - ax) < 25)
+    c.flag = 2;
+  else
+    c.flag = 0;
+  cand[(int64_t)p * kCandSlots + kNumCand] = c;
 }
 
 // Exact integer moments of two uint16 rows, 8 pixels per lane and step.  Pixels
@@ -956,14 +1283,14 @@ __device__ __forceinline__ void reduce_moments(unsigned long long (&v)[5], unsig
 }
 
 // Exact moments (sum a, sum b, sum a^2, sum b^2, sum ab) over the overlap of a
-// candidate shift.  grid (kNccChunks, kNumCand, pairs_in_pass).
+// candidate shift.  grid (kNccChunks, kCandSlots, pairs_in_pass).
 __global__ __launch_bounds__(kThreads) void k_ncc_accumulate(const PairDesc* desc, const int8_t* status,
                                                              int pair0, const Cand* cand,
                                                              unsigned long long* acc) {
   __shared__ unsigned long long red[5 * kThreads / 64];
   const int p = pair0 + blockIdx.z;
   if (status[p] != MISTITCH_PAIR_OK) return;
-  const Cand c = cand[(int64_t)p * kNumCand + blockIdx.y];
+  const Cand c = cand[(int64_t)p * kCandSlots + blockIdx.y];
   if (c.flag != 0) return;
   const PairDesc d = desc[p];
   const int ds = d.transposed ? c.x : c.y;
@@ -974,7 +1301,7 @@ __global__ __launch_bounds__(kThreads) void k_ncc_accumulate(const PairDesc* des
   unsigned long long v[5];
   moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, s_lo + blockIdx.x, s_hi,
                   gridDim.x, l_hi - l_lo, v);
-  reduce_moments(v, red, acc + ((int64_t)p * kNumCand + blockIdx.y) * 5);
+  reduce_moments(v, red, acc + ((int64_t)p * kCandSlots + blockIdx.y) * 5);
 }
 
 // ---- exact 128-bit helpers -------------------------------------------------
@@ -1018,7 +1345,7 @@ __device__ double ncc_from_moments(unsigned long long n, unsigned long long sa, 
 
 // One thread per pair walks the candidates in evaluation order.
 __global__ void k_finalize(const PairDesc* desc, const int8_t* status_in, int n_pairs, const Cand* cand,
-                           const unsigned long long* acc, double* out, int8_t* status) {
+                           const unsigned long long* acc, double* out, int8_t* status, const UpsState* ups) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
   if (status_in[p] != MISTITCH_PAIR_OK) {
@@ -1031,7 +1358,7 @@ __global__ void k_finalize(const PairDesc* desc, const int8_t* status_in, int n_
   int by = 0, bx = 0;
   double vals[kNumCand];
   for (int c = 0; c < kNumCand; ++c) {
-    const Cand k = cand[(int64_t)p * kNumCand + c];
+    const Cand k = cand[(int64_t)p * kCandSlots + c];
     double v;
     if (k.flag == 1) {
       vals[c] = -INFINITY;
@@ -1041,7 +1368,7 @@ __global__ void k_finalize(const PairDesc* desc, const int8_t* status_in, int n_
     } else if (k.flag == 3) {
       v = vals[k.dup_of];
     } else {
-      const unsigned long long* m = acc + ((int64_t)p * kNumCand + c) * 5;
+      const unsigned long long* m = acc + ((int64_t)p * kCandSlots + c) * 5;
       const int ay = k.y < 0 ? -k.y : k.y, ax = k.x < 0 ? -k.x : k.x;
       const unsigned long long n = (unsigned long long)(d.img_h - ay) * (unsigned long long)(d.img_w - ax);
       v = ncc_from_moments(n, m[0], m[1], m[2], m[3], m[4]);
@@ -1053,9 +1380,26 @@ __global__ void k_finalize(const PairDesc* desc, const int8_t* status_in, int n_
       bx = k.x;
     }
   }
+  double oy = (double)by, ox = (double)bx;
+  if (ups != nullptr && ups[p].valid) {
+    // The subpixel estimate is scored at its rounded position and is listed BEFORE the
+    // discrete result (_translation_computation.py:1232-1313): it wins unless strictly worse.
+    const Cand k = cand[(int64_t)p * kCandSlots + kNumCand];
+    if (k.flag == 0) {
+      const unsigned long long* m = acc + ((int64_t)p * kCandSlots + kNumCand) * 5;
+      const int ay = k.y < 0 ? -k.y : k.y, ax = k.x < 0 ? -k.x : k.x;
+      const unsigned long long n = (unsigned long long)(d.img_h - ay) * (unsigned long long)(d.img_w - ax);
+      const double v = ncc_from_moments(n, m[0], m[1], m[2], m[3], m[4]);
+      if (v != -INFINITY && v >= best) {
+        best = v;
+        oy = d.transposed ? ups[p].sub_l : ups[p].sub_s;
+        ox = d.transposed ? ups[p].sub_s : ups[p].sub_l;
+      }
+    }
+  }
   out[3 * p] = best;
-  out[3 * p + 1] = (double)(by + d.off_y);
-  out[3 * p + 2] = (double)(bx + d.off_x);
+  out[3 * p + 1] = oy + (double)d.off_y;
+  out[3 * p + 2] = ox + (double)d.off_x;
   if (best == -INFINITY) status[p] = MISTITCH_PAIR_NO_CANDIDATE;
 }
 
@@ -1233,6 +1577,8 @@ struct ShapeCfg {
   const uint16_t* stored_pos;   // device: positions k_fft_short_cps wrote, ascending
   const uint16_t* mirror_fill;  // device: per stored position, the position that is its conjugate (0xffff: none)
   int n_stored;
+  const uint16_t* pos2stored;  // device: position -> index in stored_pos (0xffff: not stored)
+  const KappaEntry* kappa;     // device: the stored column of every |frequency| 0 .. L/2 (subpixel stage)
   int NF_fwd;  // lines per k_fft_long_fwd block
   int NF_inv;  // line pairs per k_fft_long_inv block
   size_t lds_fwd, lds_cps, lds_inv;
@@ -1279,19 +1625,39 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   cfg->lds_cps = ((size_t)S * 2 * C + (f64 ? Twiddles<double>::entries(S) : Twiddles<float>::entries(S))) * esz;
   MS_REQUIRE(cfg->lds_cps <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "short side %d needs %zu B of LDS", S, cfg->lds_cps);
   {
+    std::vector<uint16_t> pos2freq(L), pos2stored(L, 0xffff);
+    MS_HIP(hipMemcpy(pos2freq.data(), cfg->planL.pos2freq, (size_t)L * 2, hipMemcpyDeviceToHost));
+    std::vector<KappaEntry> kappa(L / 2 + 1, KappaEntry{0xffff, 1, 0});
+    for (size_t i = 0; i < stored_pos.size(); ++i) {
+      const int pos = stored_pos[i];
+      pos2stored[pos] = (uint16_t)i;
+      const int f = pos2freq[pos];
+      const int k = f < L / 2 ? f : f - L;  // Nyquist counts as negative
+      const int a = k < 0 ? -k : k;
+      if (kappa[a].stored != 0xffff) continue;  // both columns of the pair are stored: one represents it
+      kappa[a] = KappaEntry{(uint16_t)i, (int8_t)(k < 0 ? -1 : 1), (int8_t)(mpos[pos] == pos ? 1 : 0)};
+    }
+    for (const KappaEntry& k : kappa)
+      MS_REQUIRE(k.stored != 0xffff, MISTITCH_ERR_UNSUPPORTED, "a conjugate pair of columns is not stored (L = %d)", L);
     const size_t ub = units.size() * sizeof(CpsUnit), sb = stored_pos.size() * sizeof(uint16_t);
+    const size_t ub_pad = (ub + 15) / 16 * 16, sb_pad = (sb + 15) / 16 * 16, pb = ((size_t)L * 2 + 15) / 16 * 16;
+    const size_t kb = kappa.size() * sizeof(KappaEntry);
     void* blob = nullptr;
-    MS_HIP(hipMalloc(&blob, ub + 2 * sb));
+    MS_HIP(hipMalloc(&blob, ub_pad + 2 * sb_pad + pb + kb));
     ctx->shape_allocs.push_back(blob);
     char* base = reinterpret_cast<char*>(blob);
     MS_HIP(hipMemcpy(base, units.data(), ub, hipMemcpyHostToDevice));
-    MS_HIP(hipMemcpy(base + ub, stored_pos.data(), sb, hipMemcpyHostToDevice));
-    MS_HIP(hipMemcpy(base + ub + sb, mirror_fill.data(), sb, hipMemcpyHostToDevice));
+    MS_HIP(hipMemcpy(base + ub_pad, stored_pos.data(), sb, hipMemcpyHostToDevice));
+    MS_HIP(hipMemcpy(base + ub_pad + sb_pad, mirror_fill.data(), sb, hipMemcpyHostToDevice));
+    MS_HIP(hipMemcpy(base + ub_pad + 2 * sb_pad, pos2stored.data(), (size_t)L * 2, hipMemcpyHostToDevice));
+    MS_HIP(hipMemcpy(base + ub_pad + 2 * sb_pad + pb, kappa.data(), kb, hipMemcpyHostToDevice));
     cfg->units = reinterpret_cast<const CpsUnit*>(base);
     cfg->n_units = (int)units.size();
-    cfg->stored_pos = reinterpret_cast<const uint16_t*>(base + ub);
-    cfg->mirror_fill = reinterpret_cast<const uint16_t*>(base + ub + sb);
+    cfg->stored_pos = reinterpret_cast<const uint16_t*>(base + ub_pad);
+    cfg->mirror_fill = reinterpret_cast<const uint16_t*>(base + ub_pad + sb_pad);
     cfg->n_stored = (int)stored_pos.size();
+    cfg->pos2stored = reinterpret_cast<const uint16_t*>(base + ub_pad + 2 * sb_pad);
+    cfg->kappa = reinterpret_cast<const KappaEntry*>(base + ub_pad + 2 * sb_pad + pb);
   }
   const size_t lb = f64 ? line_bytes<double>(L) : line_bytes<float>(L);
   int nf = (int)(kLdsBudget / lb);
@@ -1477,7 +1843,47 @@ struct RegWorkspace {
   Cand* cand;
   unsigned long long* acc;
   int partial_stride;
+  // subpixel stage (n_up = 0: off)
+  int n_up = 0;
+  double uf = 0.0;
+  UpsState* ups = nullptr;        // [pairs]
+  Peak* partial_abs = nullptr;    // [chunk][abs_stride]
+  int abs_stride = 0;
+  Peak* partial_ups = nullptr;    // [chunk][n_row_blocks]
+  int n_row_blocks = 0;
+  double2* nq = nullptr;          // [chunk][n_stored_max]
+  double2* t1 = nullptr;          // [chunk][n_up][n_stored_max]
+  int n_stored_max = 0;
 };
+
+// Carve the subpixel buffers out of the context's workspace.
+static int reserve_subpixel(mistitch_ctx* ctx, int n_pairs, int chunk, int abs_stride, int n_stored_max, int uf,
+                            RegWorkspace* ws) {
+  const int n_up = (3 * uf + 1) / 2;  // ceil(1.5 uf)
+  MS_REQUIRE(uf >= 2 && n_up <= kUpsMax, MISTITCH_ERR_UNSUPPORTED, "upsample factor %d outside [2, %d]", uf,
+             2 * kUpsMax / 3);
+  const int n_row_blocks = (n_up + kUpsRows - 1) / kUpsRows;
+  auto pad = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t b_ups = pad((size_t)n_pairs * sizeof(UpsState));
+  const size_t b_abs = pad((size_t)chunk * abs_stride * sizeof(Peak));
+  const size_t b_pu = pad((size_t)chunk * n_row_blocks * sizeof(Peak));
+  const size_t b_nq = pad((size_t)chunk * n_stored_max * sizeof(double2));
+  const size_t b_t1 = pad((size_t)chunk * n_up * n_stored_max * sizeof(double2));
+  int rc;
+  if ((rc = ctx->ups.reserve(b_ups + b_abs + b_pu + b_nq + b_t1))) return rc;
+  char* base = reinterpret_cast<char*>(ctx->ups.ptr);
+  ws->n_up = n_up;
+  ws->uf = (double)uf;
+  ws->ups = reinterpret_cast<UpsState*>(base);
+  ws->partial_abs = reinterpret_cast<Peak*>(base + b_ups);
+  ws->abs_stride = abs_stride;
+  ws->partial_ups = reinterpret_cast<Peak*>(base + b_ups + b_abs);
+  ws->n_row_blocks = n_row_blocks;
+  ws->nq = reinterpret_cast<double2*>(base + b_ups + b_abs + b_pu);
+  ws->t1 = reinterpret_cast<double2*>(base + b_ups + b_abs + b_pu + b_nq);
+  ws->n_stored_max = n_stored_max;
+  return MISTITCH_OK;
+}
 
 static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, size_t staging_elems_per_pair,
                                 size_t spectrum_bytes_per_pair, size_t slab_bytes_per_pair, int partial_stride,
@@ -1489,8 +1895,8 @@ static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, size_
   if ((rc = ctx->slabs.reserve((size_t)chunk * slab_bytes_per_pair))) return rc;
   if ((rc = ctx->partial.reserve((size_t)chunk * partial_stride * sizeof(Peak)))) return rc;
   if ((rc = ctx->peaks.reserve((size_t)n_pairs * kMaxK * sizeof(Peak)))) return rc;
-  if ((rc = ctx->cand.reserve((size_t)n_pairs * kNumCand * sizeof(Cand)))) return rc;
-  if ((rc = ctx->acc.reserve((size_t)n_pairs * kNumCand * 5 * sizeof(unsigned long long)))) return rc;
+  if ((rc = ctx->cand.reserve((size_t)n_pairs * kCandSlots * sizeof(Cand)))) return rc;
+  if ((rc = ctx->acc.reserve((size_t)n_pairs * kCandSlots * 5 * sizeof(unsigned long long)))) return rc;
   ws->desc = (PairDesc*)ctx->desc.ptr;
   ws->staging = (uint16_t*)ctx->staging.ptr;
   ws->spectrum = ctx->spectrum.ptr;
@@ -1522,12 +1928,28 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
   if ((rc = allow_lds(ctx, k_fft_short_cps<T>, cfg.lds_cps))) return rc;
   const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
   MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<T>), dim3(cfg.n_units, n), dim3(kThreads), cfg.lds_cps, ws.desc, status,
-            pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps);
+            pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps,
+            ws.n_up ? slabs : (cx<T>*)nullptr);
   if ((rc = allow_lds(ctx, k_fft_long_inv<T>, cfg.lds_inv))) return rc;
   MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv<T>), dim3(cfg.S / (2 * cfg.NF_inv), n), dim3(kThreads), cfg.lds_inv, ws.desc,
                      status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored,
             cfg.NF_inv, spec, k, ws.partial,
-                     ws.partial_stride, pcm_out);
+                     ws.partial_stride, pcm_out, ws.n_up ? ws.partial_abs : (Peak*)nullptr, ws.abs_stride);
+  if (ws.n_up) {
+    // subpixel refinement of these pairs, while their normalised spectra still sit in the slab buffer
+    const int nblk = cfg.S / (2 * cfg.NF_inv);
+    MS_REQUIRE(k >= 1 && k <= 2, MISTITCH_ERR_UNSUPPORTED, "the subpixel stage needs the two-peak search");
+    MS_LAUNCH(ctx, "k_ups_coarse", k_ups_coarse, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S, cfg.L,
+              want_transposed, ws.partial_abs, ws.abs_stride, nblk, ws.ups);
+    const size_t lds_ups = (size_t)cfg.S * 2 * cfg.C * sizeof(cx<T>);
+    if ((rc = allow_lds(ctx, k_ups_short<T>, lds_ups))) return rc;
+    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T>), dim3(cfg.n_units, n), dim3(kThreads), lds_ups, ws.desc, status, pair0, cfg.S,
+              cfg.L, want_transposed, cfg.planS, cfg.units, cfg.pos2stored, ws.n_stored_max, slabs, ws.ups, ws.n_up, ws.uf,
+              ws.t1, ws.nq);
+    MS_LAUNCH(ctx, "k_ups_long", k_ups_long, dim3(ws.n_row_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S, cfg.L,
+              want_transposed, cfg.kappa, ws.n_stored_max, ws.t1, ws.nq, ws.ups, ws.n_up, ws.uf, ws.partial_ups,
+              ws.n_row_blocks);
+  }
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }
@@ -1560,7 +1982,11 @@ static int launch_fft_general(mistitch_ctx* ctx, const GenShape& g, const RegWor
 
 static int launch_any(mistitch_ctx* ctx, const AnyShape& a, bool f64, const RegWorkspace& ws, const int8_t* status,
                       int pair0, int n, int want_transposed, bool vec_ok, int k, double* pcm_out) {
-  if (a.general) return launch_fft_general(ctx, a.gen, ws, status, pair0, n, want_transposed, k, pcm_out);
+  if (a.general) {
+    MS_REQUIRE(ws.n_up == 0, MISTITCH_ERR_UNSUPPORTED,
+               "subpixel refinement needs strips with power-of-two sides (got %d x %d)", a.S, a.L);
+    return launch_fft_general(ctx, a.gen, ws, status, pair0, n, want_transposed, k, pcm_out);
+  }
   return f64 ? launch_fft<double>(ctx, a.fast, ws, status, pair0, n, want_transposed, vec_ok, k, pcm_out)
              : launch_fft<float>(ctx, a.fast, ws, status, pair0, n, want_transposed, vec_ok, k, pcm_out);
 }
@@ -1623,6 +2049,14 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
   RegWorkspace ws;
   const size_t slab = std::max(cfg_left.slab_bytes, cfg_top.slab_bytes);
   if ((rc = reserve_registration(ctx, n_pairs, chunk, (size_t)w_left * H * 2, spec, slab, pstride, &ws))) return rc;
+  const bool subpixel = (flags & MISTITCH_REG_SUBPIXEL) != 0;
+  if (subpixel) {
+    MS_REQUIRE(!cfg_left.general && !cfg_top.general, MISTITCH_ERR_UNSUPPORTED,
+               "subpixel refinement needs strips with power-of-two sides");
+    if ((rc = reserve_subpixel(ctx, n_pairs, chunk, std::max(cfg_left.nblk, cfg_top.nblk),
+                               std::max(cfg_left.fast.n_stored, cfg_top.fast.n_stored), ctx->upsample_factor, &ws)))
+      return rc;
+  }
   // 16-byte loads of tile rows need aligned rows; staging lines always are.
   const bool vec_top = aligned16(tiles) && (W % 8 == 0) && (tile_pitch % 8 == 0);
   const int k = 2;  // peaks the candidate search consumes
@@ -1648,19 +2082,31 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
     }
     MS_LAUNCH(ctx, "k_peaks_candidates", k_peaks_candidates, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, ws.partial,
                        ws.partial_stride, cfg_top.nblk, cfg_left.nblk, k, 2, ws.peaks, ws.cand, ws.acc);
-    MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(kNccChunks, kNumCand, n), dim3(kThreads), 0, ws.desc, status, pair0,
+    if (subpixel)
+      MS_LAUNCH(ctx, "k_ups_finish", k_ups_finish, dim3((n + 63) / 64), dim3(64), 0, ws.desc, status, pair0, n, ws.partial_ups,
+                ws.n_row_blocks, ws.n_up, ws.uf, ws.ups, ws.cand);
+    MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(kNccChunks, kCandSlots, n), dim3(kThreads), 0, ws.desc, status, pair0,
                        ws.cand, ws.acc);
   }
   MS_LAUNCH(ctx, "k_finalize", k_finalize, dim3((n_pairs + 63) / 64), dim3(64), 0, ws.desc, status, n_pairs, ws.cand, ws.acc,
-                     out, status);
+                     out, status, subpixel ? ws.ups : (const UpsState*)nullptr);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }
 
 // Shared body of mistitch_pcm / mistitch_pcm_topk: one pair of free-standing strips.
+__global__ void k_ups_to_array(const PairDesc* desc, const UpsState* ups, double* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const PairDesc d = desc[0];
+  const UpsState u = ups[0];
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  out[0] = u.valid ? (d.transposed ? u.sub_l : u.sub_s) : nan;
+  out[1] = u.valid ? (d.transposed ? u.sub_s : u.sub_l) : nan;
+}
+
 static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1, const uint16_t* strip2,
                            int64_t pitch2, int h, int w, unsigned flags, int k, double* out_pcm, int32_t* rows,
-                           int32_t* cols, double* vals) {
+                           int32_t* cols, double* vals, int upsample = 0, double* sub_out = nullptr) {
   MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
   MS_REQUIRE(strip1 && strip2, MISTITCH_ERR_ARG, "NULL strip");
   MS_REQUIRE(h > 0 && w > 0 && pitch1 >= w && pitch2 >= w, MISTITCH_ERR_ARG, "bad strip geometry");
@@ -1675,6 +2121,11 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   const int pstride = cfg.nblk * kMaxK;
   RegWorkspace ws;
   if ((rc = reserve_registration(ctx, 1, 1, (size_t)S * L, cfg.spec_bytes, cfg.slab_bytes, pstride, &ws))) return rc;
+  if (sub_out != nullptr) {
+    MS_REQUIRE(!cfg.general, MISTITCH_ERR_UNSUPPORTED, "subpixel refinement needs strips with power-of-two sides (got %d x %d)",
+               h, w);
+    if ((rc = reserve_subpixel(ctx, 1, 1, cfg.nblk, cfg.fast.n_stored, upsample, &ws))) return rc;
+  }
   if ((rc = ctx->misc.reserve(256))) return rc;
   hipStream_t st = ctx->stream;
   PairDesc d;
@@ -1714,6 +2165,13 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   MS_HIP(hipMemcpyAsync(ws.desc, &d, sizeof(d), hipMemcpyHostToDevice, st));
   MS_HIP(hipStreamSynchronize(st));  // d lives on this stack frame
   if ((rc = launch_any(ctx, cfg, f64, ws, status, 0, 1, -1, vec, k, out_pcm))) return rc;
+  if (sub_out != nullptr) {
+    MS_LAUNCH(ctx, "k_ups_finish", k_ups_finish, dim3(1), dim3(64), 0, ws.desc, status, 0, 1, ws.partial_ups, ws.n_row_blocks,
+              ws.n_up, ws.uf, ws.ups, ws.cand);
+    MS_LAUNCH(ctx, "k_ups_to_array", k_ups_to_array, dim3(1), dim3(64), 0, ws.desc, ws.ups, sub_out);
+    MS_HIP(hipGetLastError());
+    return MISTITCH_OK;
+  }
   if (k > 0) {
     MS_LAUNCH(ctx, "k_peaks_candidates", k_peaks_candidates, dim3(1), dim3(kThreads), 0, ws.desc, status, 0, ws.partial,
                        ws.partial_stride, cfg.nblk, cfg.nblk, k, 0, ws.peaks,
@@ -1736,6 +2194,22 @@ extern "C" int mistitch_pcm_topk(mistitch_ctx* ctx, const uint16_t* strip1, int6
   MS_REQUIRE(rows && cols && vals, MISTITCH_ERR_ARG, "NULL output array");
   MS_REQUIRE(k >= 1 && k <= kMaxK, MISTITCH_ERR_ARG, "k must be in [1, %d]", kMaxK);
   return single_pair_pcm(ctx, strip1, pitch1, strip2, pitch2, h, w, flags, k, nullptr, rows, cols, vals);
+}
+
+extern "C" int mistitch_subpixel_shift(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1, const uint16_t* strip2,
+                                       int64_t pitch2, int h, int w, unsigned flags, int upsample_factor,
+                                       double* out_shift) {
+  MS_REQUIRE(out_shift, MISTITCH_ERR_ARG, "out_shift is NULL");
+  return single_pair_pcm(ctx, strip1, pitch1, strip2, pitch2, h, w, flags, 2, nullptr, nullptr, nullptr, nullptr,
+                         upsample_factor, out_shift);
+}
+
+extern "C" int mistitch_set_upsample_factor(mistitch_ctx* ctx, int upsample_factor) {
+  MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
+  MS_REQUIRE(upsample_factor >= 2 && (3 * upsample_factor + 1) / 2 <= kUpsMax, MISTITCH_ERR_UNSUPPORTED,
+             "upsample factor %d outside [2, %d]", upsample_factor, 2 * kUpsMax / 3);
+  ctx->upsample_factor = upsample_factor;
+  return MISTITCH_OK;
 }
 
 extern "C" int mistitch_ncc(mistitch_ctx* ctx, const uint16_t* patch1, int64_t pitch1, const uint16_t* patch2,

@@ -16,7 +16,7 @@ from typing import Dict, List, Optional, Sequence, Set, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import FFT_F32, FFT_F64, PAIR_FEATURELESS, PAIR_NO_CANDIDATE, PAIR_OK, check, lib, ptr
+from ._lib import FFT_F32, FFT_F64, PAIR_FEATURELESS, PAIR_NO_CANDIDATE, PAIR_OK, REG_SUBPIXEL, check, lib, ptr
 
 logger = logging.getLogger(__name__)
 
@@ -73,7 +73,8 @@ def to_device_u16(arr, device=None):
 # batched seam
 # ----------------------------------------------------------------------------
 def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WIDTH, fft: str = "f64",
-                   ctx: Optional[_lib.Context] = None, out=None, status=None):
+                   ctx: Optional[_lib.Context] = None, out=None, status=None, subpixel: bool = False,
+                   upsample_factor: int = 100):
     """Register every (first, second) tile pair on the device.
 
     tiles     [N, H, W] uint16 CUDA tensor (or NumPy array, uploaded)
@@ -82,6 +83,9 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
     pair_dir  [P] uint8
     Returns (out [P, 3] float64 CUDA tensor: ncc, y, x; status [P] int8 CUDA tensor).
     Rows of featureless pairs are NaN, as the reference leaves them in its grid.
+    ``subpixel`` adds the upsampled-DFT estimate (SubpixelConfig(upsample_factor=100,
+    use_subpixel=True) at tile_registration.py:574) as the reference does when
+    scikit-image is installed; y and x are then fractional.
     """
     torch = _torch()
     tiles = to_device_u16(tiles)
@@ -101,8 +105,12 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
         status = torch.empty((n_pairs,), dtype=torch.int8, device=dev)
     ctx = ctx or _lib.default_context()
     n, h, w = (int(s) for s in tiles.shape)
+    flags = _fft_flag(fft)
+    if subpixel:
+        ctx.set_upsample_factor(upsample_factor)
+        flags |= REG_SUBPIXEL
     check(lib.mistitch_register_pairs(ctx.handle, ptr(tiles), n, h, w, h * w, ptr(pi), ptr(pd_), n_pairs,
-                                      int(edge_width), _fft_flag(fft), ptr(out), ptr(status)))
+                                      int(edge_width), flags, ptr(out), ptr(status)))
     return out, status
 
 
@@ -216,6 +224,22 @@ def pcm_topk(image1: np.ndarray, image2: np.ndarray, k: int = 2, fft: str = "f64
     check(lib.mistitch_pcm_topk(ctx.handle, ptr(a), w, ptr(b), w, h, w, _fft_flag(fft), int(k),
                                 ptr(rows), ptr(cols), ptr(vals)))
     return rows.cpu().numpy().astype(np.int64), cols.cpu().numpy().astype(np.int64), vals.cpu().numpy()
+
+
+def phase_cross_correlation(reference_image: np.ndarray, moving_image: np.ndarray, upsample_factor: int = 100,
+                            fft: str = "f64") -> np.ndarray:
+    """Shift (dy, dx) registering ``moving_image`` onto ``reference_image`` by upsampled DFT: what
+    ``skimage.registration.phase_cross_correlation(a, b, upsample_factor=u, normalization='phase')``
+    returns as its first result, as called at _translation_computation.py:1239-1247."""
+    torch = _torch()
+    _validate_pair(reference_image, moving_image)
+    a, b = to_device_u16(reference_image), to_device_u16(moving_image)
+    h, w = (int(s) for s in a.shape)
+    out = torch.empty((2,), dtype=torch.float64, device=a.device)
+    ctx = _lib.default_context()
+    check(lib.mistitch_subpixel_shift(ctx.handle, ptr(a), w, ptr(b), w, h, w, _fft_flag(fft), int(upsample_factor),
+                                      ptr(out)))
+    return out.cpu().numpy()
 
 
 def ncc(image1: np.ndarray, image2: np.ndarray, min_overlap_pixels: int = 25) -> float:

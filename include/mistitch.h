@@ -40,6 +40,7 @@ extern "C" {
 /* flags */
 #define MISTITCH_FFT_F64 0u /* complex128 spectra, as the reference computes them (default) */
 #define MISTITCH_FFT_F32 1u /* complex64 spectra: half the traffic, PCM differs at ~1e-7     */
+#define MISTITCH_REG_SUBPIXEL 2u /* mistitch_register_pairs: add the upsampled-DFT estimate    */
 
 /* fusion modes */
 #define MISTITCH_FUSE_OVERWRITE 0 /* last writer wins, the reference behaviour */
@@ -88,6 +89,12 @@ int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int
  *              the first tile's frame; NaN row when status is FEATURELESS
  *   status     [n_pairs] int8: MISTITCH_PAIR_*
  *
+ * With MISTITCH_REG_SUBPIXEL in `flags` the upsampled-DFT estimate (see
+ * mistitch_subpixel_shift) is scored by NCC at its rounded position and competes
+ * with the discrete search as "Method 2" does in the reference when scikit-image
+ * is installed (_translation_computation.py:1232-1320): it wins unless strictly
+ * worse, and y, x are then fractional.
+ *
  * Strips whose sides are powers of two (long side 8..4096, short side 8..1024)
  * take the Hermitian radix-16 path; any other side lengths up to 4096 take
  * chirp-z transforms (complex128 whatever `flags` says, several times slower).
@@ -96,6 +103,21 @@ int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tile
                             int tile_w, int64_t tile_pitch, const int32_t* pair_idx,
                             const uint8_t* pair_dir, int n_pairs, int edge_width, unsigned flags,
                             double* out, int8_t* status);
+
+/* Subpixel shift between two equal-shape uint16 strips by upsampled DFT: the
+ * coarse shift is the largest |PCM| value, refined on a ceil(1.5 u) square grid
+ * of spacing 1/u.  Replaces skimage.registration.phase_cross_correlation(a, b,
+ * upsample_factor=u, normalization='phase') as the reference calls it
+ * (_translation_computation.py:1233-1272).  Power-of-two strip sides only;
+ * 2 <= u <= 106.
+ *   out_shift  [2] float64: (dy, dx)                                               */
+int mistitch_subpixel_shift(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1,
+                            const uint16_t* strip2, int64_t pitch2, int h, int w, unsigned flags,
+                            int upsample_factor, double* out_shift);
+
+/* Upsample factor used by mistitch_register_pairs with MISTITCH_REG_SUBPIXEL
+ * (default 100, SubpixelConfig.upsample_factor at tile_registration.py:574). */
+int mistitch_set_upsample_factor(mistitch_ctx* ctx, int upsample_factor);
 
 /* Peak correlation matrix of two equal-shape uint16 strips.
  * Replaces pcm() (registration/_translation_computation.py:282-340).

@@ -175,3 +175,49 @@ def test_process_neighborhood_batch_mirror(reg, golden):
         for d in exp[k]:
             assert res[k][d]["y"] == exp[k][d]["y"] and res[k][d]["x"] == exp[k][d]["x"]
             assert res[k][d]["ncc"] == pytest.approx(exp[k][d]["ncc"], abs=1e-12)
+
+
+def _subpixel_pair(seed, h, w, dy, dx):
+    """Two uint16 strips cut from one smooth scene that was resampled with a fractional offset."""
+    rng = np.random.default_rng(seed)
+    big = rng.random((h + 32, w + 32))
+    k = np.fft.fftfreq(h + 32)[:, None] ** 2 + np.fft.fftfreq(w + 32)[None, :] ** 2
+    low = np.fft.ifft2(np.fft.fft2(big) * np.exp(-k * 4.0)).real  # mild low-pass, still broadband (phase correlation whitens the spectrum)
+    fy, fx = np.fft.fftfreq(h + 32)[:, None], np.fft.fftfreq(w + 32)[None, :]
+    moved = np.fft.ifft2(np.fft.fft2(low) * np.exp(-2j * np.pi * (fy * dy + fx * dx))).real
+    def to_u16(img):
+        img = (img - low.min()) / (low.max() - low.min())
+        return np.clip(1000 + 50000 * img, 0, 65535).astype(np.uint16)
+    return (np.ascontiguousarray(to_u16(low)[16:16 + h, 16:16 + w]),
+            np.ascontiguousarray(to_u16(moved)[16:16 + h, 16:16 + w]))
+
+
+@pytest.mark.parametrize("fft", ["f64", "f32"])
+def test_subpixel_shift_matches_upsampled_dft_oracle(reg, fft):
+    """Within 0.01 px of the NumPy restatement of scikit-image's algorithm (parity unpinned:
+    scikit-image itself is not installed here), and close to the planted fractional shift."""
+    from oracle import subpixel as osp
+    for seed, (h, w, dy, dx) in enumerate([(64, 256, 0.37, -1.24), (256, 64, -2.5, 3.75), (128, 512, 0.0, 0.49),
+                                           (32, 1024, 3.21, -7.68)]):
+        a, b = _subpixel_pair(40 + seed, h, w, dy, dx)
+        want = osp.phase_cross_correlation(a, b, 100)
+        got = reg.phase_cross_correlation(a, b, 100, fft=fft)
+        assert np.abs(got - want).max() <= 0.01 + 1e-9, (h, w, got, want)
+        assert np.abs(got - np.array([-dy, -dx])).max() < 0.1, (got, dy, dx)
+    a, b = _subpixel_pair(77, 64, 256, 1.3, 0.2)
+    assert np.abs(reg.phase_cross_correlation(a, b, 10) - osp.phase_cross_correlation(a, b, 10)).max() <= 0.1 + 1e-9
+
+
+def test_register_pairs_with_subpixel_candidate(reg):
+    """The subpixel estimate competes as the reference's Method 2 does (listed first, wins ties)."""
+    from oracle import subpixel as osp
+    g = synth.make_grid(31, 2, 3, 512, 512, overlap=0.12, jitter=3)
+    ref, ref_status, _ = osp.register_pairs_subpixel(g.tiles, g.pair_idx, g.pair_dir, 64)
+    out, status = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 64, subpixel=True)
+    out, status = out.cpu().numpy(), status.cpu().numpy()
+    assert np.array_equal(status != 0, ref_status != 0)
+    assert np.abs(out[:, 1:] - ref[:, 1:]).max() <= 0.01 + 1e-9
+    assert np.allclose(out[:, 0], ref[:, 0], rtol=0, atol=1e-12)
+    # without the flag the integer result of the discrete search is unchanged
+    plain, _ = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 64)
+    assert np.array_equal(np.rint(out[:, 1:]), plain.cpu().numpy()[:, 1:])
