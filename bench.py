@@ -217,6 +217,15 @@ def main():
                                           ptr(d_pair_idx), ptr(d_pair_dir), n_pairs, edge, other_fft_flag,
                                           ptr(d_out2), ptr(d_status2)))
 
+    def step_registration_subpixel():
+        """The configured step with the upsampled-DFT estimate added for every pair."""
+        if ffs is not None:
+            check(lib.mistitch_apply_flatfield(ctx.handle, ptr(tiles[0]), ptr(ffs[0]), ff_type, ptr(reg_tiles),
+                                               n_tiles, tile, tile))
+        check(lib.mistitch_register_pairs(ctx.handle, ptr(reg_tiles), n_tiles, tile, tile, tile * tile,
+                                          ptr(d_pair_idx), ptr(d_pair_dir), n_pairs, edge, fft_flag | _lib.REG_SUBPIXEL,
+                                          ptr(d_out2), ptr(d_status2)))
+
     def fuse(mode):
         check(lib.mistitch_fuse(ctx.handle, ptr(tiles), ch * n_tiles, tile, tile, tile * tile, ptr(d_yx), ptr(d_plane),
                                 ptr(ffs), ff_type, ptr(d_plane) if ffs is not None else ptr(None), ptr(mosaic), ch,
@@ -259,6 +268,9 @@ def main():
         step_registration_other()
         t_reg_other = timed(step_registration_other, args.steps)
         out2_np, st2_np = d_out2.cpu().numpy(), d_status2.cpu().numpy()
+        step_registration_subpixel()
+        t_reg_sub = timed(step_registration_subpixel, args.steps)
+        out3_np = d_out2.cpu().numpy()
 
     # ---- parity properties at full size: every planted shift recovered, mosaic spot checks ----
     out_np, st_np = d_out.cpu().numpy(), d_status.cpu().numpy()
@@ -278,6 +290,12 @@ def main():
         for name, (ms, launches) in ctx.profile_collect().items():
             kernels[name] = dict(ms_per_step=ms / psteps, launches_per_step=launches / psteps,
                                  avg_launch_us=1e3 * ms / launches)
+        if side:  # the subpixel stage's own kernels, from a separate pass so the figures above stay those of the configured step
+            ctx.profile_collect()
+            step_registration_subpixel()
+            for name, (ms, launches) in ctx.profile_collect().items():
+                if name.startswith("k_ups_"):
+                    kernels[name] = dict(ms_per_step=ms, launches_per_step=float(launches), avg_launch_us=1e3 * ms / launches)
         ctx.profile(False)
 
     # ---- algorithmic bytes ----
@@ -376,6 +394,11 @@ def main():
                 "value": round(pairs_per_s_other, 1), "unit": "tile-pairs/s",
                 "ms_per_step": round(1e3 * t_reg_other / args.steps, 3),
                 "planted_integer_shifts_recovered": shifts_ok_other}
+        if side:
+            line["registration_subpixel"] = {
+                "value": round(world * n_pairs * args.steps / t_reg_sub, 1), "unit": "tile-pairs/s",
+                "ms_per_step": round(1e3 * t_reg_sub / args.steps, 3), "upsample_factor": 100,
+                "max_abs_shift_error_px": float(np.abs(out3_np[:, 1:] - expected).max())}
         if cpu is not None:
             cpu_pairs_s = cpu["pairs"] / cpu["t_reg"]
             line["cpu_baseline"] = {

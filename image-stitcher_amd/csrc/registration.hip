@@ -48,7 +48,7 @@ constexpr int kNumCand = 32;    // 2 peaks x 16 signed interpretations
 constexpr int kNccChunks = 32;  // workgroups cooperating on one candidate
 constexpr int kCandSlots = kNumCand + 1;  // the last slot holds the subpixel estimate's rounded shift (flag 1 when unused)
 constexpr int kUpsMax = 160;    // largest upsampled region side (ceil(1.5 * upsample factor))
-constexpr int kUpsRows = 10;    // upsampled rows per block of the second stage
+constexpr int kUpsRows = 15;    // upsampled rows per block of the second stage
 
 struct PairDesc {
   const uint16_t* a;  // canonical strip of the first tile
@@ -979,6 +979,27 @@ struct KappaEntry {
   int8_t self;      // 1: the column is its own conjugate partner (kappa = 0 or L / 2)
 };
 
+// X_b for the NA columns of a unit held in LDS, rows in ascending signed frequency.
+template <typename T, int NA>
+__device__ __forceinline__ void ups_short_columns(const cx<T>* tile, int S, double2 w, double2 step, double2* out,
+                                                  const uint16_t* __restrict__ pos2stored, int a0) {
+  double2 acc[NA];
+#pragma unroll
+  for (int c = 0; c < NA; ++c) acc[c] = mk<double>(0.0, 0.0);
+  for (int kk = 0; kk < S; ++kk) {
+    const cx<T>* row = tile + kk * NA;
+#pragma unroll
+    for (int c = 0; c < NA; ++c) {
+      const double rx = (double)row[c].x, ry = (double)row[c].y;
+      acc[c].x += rx * w.x - ry * w.y;
+      acc[c].y += rx * w.y + ry * w.x;
+    }
+    w = cmul(w, step);
+  }
+#pragma unroll
+  for (int c = 0; c < NA; ++c) out[pos2stored[a0 + c]] = acc[c];
+}
+
 // grid (n_units, pairs_in_pass); threads 0 .. n_up-1 own one displacement each.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, const int8_t* status, int pair0, int S,
@@ -1002,16 +1023,16 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
   const int na = un.na, tid = threadIdx.x;
   const cx<T>* Rs = rslabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
   const int64_t sp = slab_pitch(S);
+  // rows land in ascending signed frequency -S/2 .. S/2-1, so the sum below walks LDS linearly
   for (int e = tid; e < S * na; e += kThreads) {
     const int q = e / na, c = e - q * na;
     const int pos = un.a0 + c;
-    tile[e] = Rs[(pos / kSlab) * sp + q * kSlab + pos % kSlab];
+    const int kk = (planS.pos2freq[q] + S / 2) & (S - 1);
+    tile[kk * na + c] = Rs[(pos / kSlab) * sp + q * kSlab + pos % kSlab];
   }
   __syncthreads();
-  double2* t1 = T1 + (int64_t)blockIdx.y * n_up * n_stored;
-  const int nyq = planS.freq2pos[S / 2];
-  if (tid < na) {
-    const cx<T> v = tile[nyq * na + tid];
+  if (tid < na) {  // the Nyquist row (signed frequency -S/2) of every column
+    const cx<T> v = tile[tid];
     Nq[(int64_t)blockIdx.y * n_stored + pos2stored[un.a0 + tid]] = mk<double>((double)v.x, (double)v.y);
   }
   if (tid >= n_up) return;
@@ -1021,28 +1042,24 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
   sincos(theta, &sn, &cs);
   const double2 step = mk<double>(cs, sn);
   sincos(theta * (double)(-(S / 2)), &sn, &cs);
-  double2 w = mk<double>(cs, sn);  // exp(i theta k), k = -S/2 first
-  constexpr int kMaxCols = 16;
-  double2 acc[kMaxCols];
-#pragma unroll
-  for (int c = 0; c < kMaxCols; ++c) acc[c] = mk<double>(0.0, 0.0);
-  for (int kk = 0; kk < S; ++kk) {
-    const int k = kk - S / 2;
-    const int pos_q = planS.freq2pos[(k + S) & (S - 1)];
-    const cx<T>* row = tile + pos_q * na;
-#pragma unroll
-    for (int c = 0; c < kMaxCols; ++c) {
-      if (c < na) {
-        const double rx = (double)row[c].x, ry = (double)row[c].y;
-        acc[c].x += rx * w.x - ry * w.y;
-        acc[c].y += rx * w.y + ry * w.x;
+  const double2 w = mk<double>(cs, sn);  // exp(i theta k), k = -S/2 first
+  double2* out = T1 + ((int64_t)blockIdx.y * n_up + tid) * n_stored;
+  if (na == 8)
+    ups_short_columns<T, 8>(tile, S, w, step, out, pos2stored, un.a0);
+  else if (na == 16)
+    ups_short_columns<T, 16>(tile, S, w, step, out, pos2stored, un.a0);
+  else {
+    for (int c = 0; c < na; ++c) {  // narrow strips: one column at a time
+      double2 acc = mk<double>(0.0, 0.0), ww = w;
+      for (int kk = 0; kk < S; ++kk) {
+        const double rx = (double)tile[kk * na + c].x, ry = (double)tile[kk * na + c].y;
+        acc.x += rx * ww.x - ry * ww.y;
+        acc.y += rx * ww.y + ry * ww.x;
+        ww = cmul(ww, step);
       }
+      out[pos2stored[un.a0 + c]] = acc;
     }
-    w = cmul(w, step);
   }
-#pragma unroll
-  for (int c = 0; c < kMaxCols; ++c)
-    if (c < na) t1[(int64_t)tid * n_stored + pos2stored[un.a0 + c]] = acc[c];
 }
 
 // grid (ceil(n_up / kUpsRows), pairs_in_pass); thread ul owns one long-axis displacement
@@ -1106,6 +1123,7 @@ __global__ __launch_bounds__(kThreads) void k_ups_long(const PairDesc* desc, con
       }
     }
     __syncthreads();
+    if ((tid & ~63) >= n_up) continue;  // a wave without displacements only helps staging
     for (int j = 0; j < nk; ++j) {
       if (!sSelf[j]) {
 #pragma unroll
