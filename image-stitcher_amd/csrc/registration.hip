@@ -516,12 +516,14 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   MS_STAMP(1, 3);
   if (keep_r != nullptr) {
     // the subpixel stage wants the normalised spectrum itself: it replaces this unit's own
-    // columns of the slab buffer, which no other workgroup reads
+    // columns of the slab buffer, which no other workgroup reads, with the rows reordered
+    // to ascending signed frequency -S/2 .. S/2-1
     cx<T>* Rs = keep_r + (int64_t)blockIdx.y * slab_pair_elems(S, L);
     for (int e = tid; e < S * na; e += kThreads) {
       const int q = e / na, c = e - q * na;
       const int pos = un.a0 + c;
-      Rs[(pos / kSlab) * sp + q * kSlab + pos % kSlab] = buf[q * rs + c];
+      const int kk = (planS.pos2freq[q] + S / 2) & (S - 1);
+      Rs[(pos / kSlab) * sp + kk * kSlab + pos % kSlab] = buf[q * rs + c];
     }
   }
   fft_inverse<T>(buf, addr, na, planS, tw, tid, kThreads);
@@ -979,28 +981,30 @@ struct KappaEntry {
   int8_t self;      // 1: the column is its own conjugate partner (kappa = 0 or L / 2)
 };
 
-// X_b for the NA columns of a unit held in LDS, rows in ascending signed frequency.
-template <typename T, int NA>
-__device__ __forceinline__ void ups_short_columns(const cx<T>* tile, int S, double2 w, double2 step, double2* out,
-                                                  const uint16_t* __restrict__ pos2stored, int a0) {
-  double2 acc[NA];
+// X_b for one whole slab (8 columns): every lane of the workgroup needs the same spectrum
+// values, so they are read through the scalar cache (constant address space, one 128-byte
+// row per step) and enter the multiply-adds as scalar operands; LDS broadcasts of the same
+// values ran four times slower.
+template <typename T>
+__device__ __forceinline__ void ups_short_slab(const cx<T>* slab, int S, double2 w, double2 step, double2 (&acc)[kSlab]) {
+  typedef const __attribute__((address_space(4))) T* scalar_ptr;
+  scalar_ptr rows = (scalar_ptr)(unsigned long long)slab;
 #pragma unroll
-  for (int c = 0; c < NA; ++c) acc[c] = mk<double>(0.0, 0.0);
+  for (int c = 0; c < kSlab; ++c) acc[c] = mk<double>(0.0, 0.0);
   for (int kk = 0; kk < S; ++kk) {
-    const cx<T>* row = tile + kk * NA;
+    scalar_ptr row = rows + kk * (2 * kSlab);
 #pragma unroll
-    for (int c = 0; c < NA; ++c) {
-      const double rx = (double)row[c].x, ry = (double)row[c].y;
+    for (int c = 0; c < kSlab; ++c) {
+      const double rx = (double)row[2 * c], ry = (double)row[2 * c + 1];
       acc[c].x += rx * w.x - ry * w.y;
       acc[c].y += rx * w.y + ry * w.x;
     }
     w = cmul(w, step);
   }
-#pragma unroll
-  for (int c = 0; c < NA; ++c) out[pos2stored[a0 + c]] = acc[c];
 }
 
-// grid (n_units, pairs_in_pass); threads 0 .. n_up-1 own one displacement each.
+// grid (n_units, pairs_in_pass); threads 0 .. n_up-1 own one displacement each.  The rows
+// of `rslabs` are in ascending signed frequency (k_fft_short_cps wrote them so).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, const int8_t* status, int pair0, int S,
                                                         int L, int want_transposed, FftPlanDev planS,
@@ -1009,8 +1013,6 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
                                                         const cx<T>* __restrict__ rslabs,
                                                         const UpsState* __restrict__ ups, int n_up, double uf,
                                                         double2* __restrict__ T1, double2* __restrict__ Nq) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  cx<T>* tile = reinterpret_cast<cx<T>*>(smem_raw);
   const int p = pair0 + blockIdx.y;
   if (status[p] != MISTITCH_PAIR_OK) return;
   {
@@ -1023,17 +1025,10 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
   const int na = un.na, tid = threadIdx.x;
   const cx<T>* Rs = rslabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
   const int64_t sp = slab_pitch(S);
-  // rows land in ascending signed frequency -S/2 .. S/2-1, so the sum below walks LDS linearly
-  for (int e = tid; e < S * na; e += kThreads) {
-    const int q = e / na, c = e - q * na;
-    const int pos = un.a0 + c;
-    const int kk = (planS.pos2freq[q] + S / 2) & (S - 1);
-    tile[kk * na + c] = Rs[(pos / kSlab) * sp + q * kSlab + pos % kSlab];
-  }
-  __syncthreads();
-  if (tid < na) {  // the Nyquist row (signed frequency -S/2) of every column
-    const cx<T> v = tile[tid];
-    Nq[(int64_t)blockIdx.y * n_stored + pos2stored[un.a0 + tid]] = mk<double>((double)v.x, (double)v.y);
+  if (tid < na) {  // the Nyquist row (signed frequency -S/2, the first row) of every column
+    const int pos = un.a0 + tid;
+    const cx<T> v = Rs[(pos / kSlab) * sp + pos % kSlab];
+    Nq[(int64_t)blockIdx.y * n_stored + pos2stored[pos]] = mk<double>((double)v.x, (double)v.y);
   }
   if (tid >= n_up) return;
   const double delta = (double)st.shift_s + ((double)tid - (double)(n_up / 2)) / uf;
@@ -1044,20 +1039,26 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
   sincos(theta * (double)(-(S / 2)), &sn, &cs);
   const double2 w = mk<double>(cs, sn);  // exp(i theta k), k = -S/2 first
   double2* out = T1 + ((int64_t)blockIdx.y * n_up + tid) * n_stored;
-  if (na == 8)
-    ups_short_columns<T, 8>(tile, S, w, step, out, pos2stored, un.a0);
-  else if (na == 16)
-    ups_short_columns<T, 16>(tile, S, w, step, out, pos2stored, un.a0);
-  else {
-    for (int c = 0; c < na; ++c) {  // narrow strips: one column at a time
+  int pos = un.a0;
+  const int end = un.a0 + na;
+  while (pos < end) {
+    if (pos % kSlab == 0 && pos + kSlab <= end) {
+      double2 acc[kSlab];
+      ups_short_slab<T>(Rs + (pos / kSlab) * sp, S, w, step, acc);
+#pragma unroll
+      for (int c = 0; c < kSlab; ++c) out[pos2stored[pos + c]] = acc[c];
+      pos += kSlab;
+    } else {  // a unit narrower than a slab: one column at a time
+      const cx<T>* col = Rs + (pos / kSlab) * sp + pos % kSlab;
       double2 acc = mk<double>(0.0, 0.0), ww = w;
       for (int kk = 0; kk < S; ++kk) {
-        const double rx = (double)tile[kk * na + c].x, ry = (double)tile[kk * na + c].y;
-        acc.x += rx * ww.x - ry * ww.y;
-        acc.y += rx * ww.y + ry * ww.x;
+        const cx<T> r = col[kk * kSlab];
+        acc.x += (double)r.x * ww.x - (double)r.y * ww.y;
+        acc.y += (double)r.x * ww.y + (double)r.y * ww.x;
         ww = cmul(ww, step);
       }
-      out[pos2stored[un.a0 + c]] = acc;
+      out[pos2stored[pos]] = acc;
+      pos += 1;
     }
   }
 }
@@ -1959,9 +1960,7 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
     MS_REQUIRE(k >= 1 && k <= 2, MISTITCH_ERR_UNSUPPORTED, "the subpixel stage needs the two-peak search");
     MS_LAUNCH(ctx, "k_ups_coarse", k_ups_coarse, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S, cfg.L,
               want_transposed, ws.partial_abs, ws.abs_stride, nblk, ws.ups);
-    const size_t lds_ups = (size_t)cfg.S * 2 * cfg.C * sizeof(cx<T>);
-    if ((rc = allow_lds(ctx, k_ups_short<T>, lds_ups))) return rc;
-    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T>), dim3(cfg.n_units, n), dim3(kThreads), lds_ups, ws.desc, status, pair0, cfg.S,
+    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T>), dim3(cfg.n_units, n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S,
               cfg.L, want_transposed, cfg.planS, cfg.units, cfg.pos2stored, ws.n_stored_max, slabs, ws.ups, ws.n_up, ws.uf,
               ws.t1, ws.nq);
     MS_LAUNCH(ctx, "k_ups_long", k_ups_long, dim3(ws.n_row_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S, cfg.L,
