@@ -738,6 +738,71 @@ __global__ __launch_bounds__(256) void k_mip(const uint16_t* __restrict__ in, in
   }
 }
 
+// Resolution pyramid: level l holds the mean of every 2^l x 2^l block of the plane
+// (blocks that would stick out of the image are dropped), as float64 - what
+// dask.array.coarsen(np.mean, image, {y: 2^l, x: 2^l}, trim_excess=True) yields for each
+// level in Stitcher.generate_pyramid (stitcher.py:652-668).  All levels come out of ONE
+// read of the image: a workgroup owns a 64 x 256 pixel tile, forms the 2 x 2 sums in
+// registers and the coarser ones through LDS; the sums are exact integers, the division by
+// 4^l exact in float64.
+constexpr int kPyrTileH = 64, kPyrTileW = 256, kPyrMaxLevels = 7;
+struct PyrLevels {
+  double* out[kPyrMaxLevels];  // [l]: level l (index 0 unused)
+};
+
+__global__ __launch_bounds__(256) void k_pyramid(const uint16_t* __restrict__ image, int H, int W, int n_levels,
+                                                 PyrLevels lv) {
+  __shared__ unsigned sums[2][kPyrTileH / 2][kPyrTileW / 2 + 1];  // ping-pong block sums of the current level
+  const int tid = threadIdx.x;
+  const int plane = blockIdx.z;
+  const int y0 = blockIdx.y * kPyrTileH, x0 = blockIdx.x * kPyrTileW;
+  const uint16_t* img = image + (int64_t)plane * H * W;
+  // level 1: thread (j, g) sums rows 2j, 2j+1 of the 8-pixel group g; 32 x 32 such cells per tile, 4 per thread
+  for (int cell = tid; cell < (kPyrTileH / 2) * (kPyrTileW / 8); cell += 256) {
+    const int j = cell / (kPyrTileW / 8), g = cell - j * (kPyrTileW / 8);
+    const int y = y0 + 2 * j, x = x0 + 8 * g;
+    unsigned px[2][8];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (y + r < H && x + 8 <= W) {
+        const Px8 v = *reinterpret_cast<const Px8*>(img + (int64_t)(y + r) * W + x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) px[r][i] = v.at(i);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) px[r][i] = (y + r < H && x + i < W) ? img[(int64_t)(y + r) * W + x + i] : 0u;
+      }
+    }
+    const int H1 = H >> 1, W1 = W >> 1;
+    const int oy = y >> 1, ox = x >> 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const unsigned sum = px[0][2 * i] + px[0][2 * i + 1] + px[1][2 * i] + px[1][2 * i + 1];
+      sums[0][j][4 * g + i] = sum;
+      if (n_levels > 1 && oy < H1 && ox + i < W1)
+        lv.out[1][((int64_t)plane * H1 + oy) * W1 + ox + i] = (double)sum * 0.25;
+    }
+  }
+  int cur = 0, th = kPyrTileH / 2, tw = kPyrTileW / 2;  // extent of the sums held in sums[cur]
+  for (int l = 2; l < n_levels; ++l) {
+    __syncthreads();
+    const int nh = th / 2, nw = tw / 2;
+    const int Hl = H >> l, Wl = W >> l;
+    const double scale = 1.0 / (double)(1u << (2 * l));
+    for (int cell = tid; cell < nh * nw; cell += 256) {
+      const int j = cell / nw, i = cell - j * nw;
+      const unsigned sum = sums[cur][2 * j][2 * i] + sums[cur][2 * j][2 * i + 1] + sums[cur][2 * j + 1][2 * i] +
+                           sums[cur][2 * j + 1][2 * i + 1];
+      sums[cur ^ 1][j][i] = sum;
+      const int oy = (y0 >> l) + j, ox = (x0 >> l) + i;
+      if (oy < Hl && ox < Wl) lv.out[l][((int64_t)plane * Hl + oy) * Wl + ox] = (double)sum * scale;
+    }
+    cur ^= 1;
+    th = nh;
+    tw = nw;
+  }
+}
+
 template <int MODE, int FF, int GX>
 static void launch_fuse(mistitch_ctx* ctx, dim3 grid, const uint16_t* tiles, int n_tiles, int H, int W, int64_t pitch,
                         const int32_t* yx, const int32_t* plane, const void* ffs, const int32_t* tff,
@@ -838,6 +903,26 @@ extern "C" int mistitch_apply_flatfield(mistitch_ctx* ctx, const uint16_t* in, c
     else
       MS_LAUNCH(ctx, "k_flatfield_tail", k_flatfield_tail<MISTITCH_FF_F64>, dim3((ntail + 63) / 64), dim3(64), 0, in, flatfield, out, npx, n_tiles);
   }
+  MS_HIP(hipGetLastError());
+  return MISTITCH_OK;
+}
+
+extern "C" int mistitch_pyramid(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int h, int w, int n_levels,
+                                double* const* levels) {
+  MS_REQUIRE(ctx && image && levels, MISTITCH_ERR_ARG, "NULL argument");
+  MS_REQUIRE(n_planes > 0 && h > 0 && w > 0, MISTITCH_ERR_ARG, "bad geometry");
+  MS_REQUIRE(n_levels >= 1 && n_levels <= kPyrMaxLevels, MISTITCH_ERR_UNSUPPORTED, "n_levels must be in [1, %d]",
+             kPyrMaxLevels);
+  if (n_levels == 1) return MISTITCH_OK;  // level 0 is the image itself
+  PyrLevels lv{};
+  for (int l = 1; l < n_levels; ++l) {
+    MS_REQUIRE(levels[l] != nullptr || (h >> l) == 0 || (w >> l) == 0, MISTITCH_ERR_ARG, "levels[%d] is NULL", l);
+    lv.out[l] = levels[l];
+  }
+  MS_HIP(hipSetDevice(ctx->device));
+  const dim3 grid((w + kPyrTileW - 1) / kPyrTileW, (h + kPyrTileH - 1) / kPyrTileH, n_planes);
+  MS_REQUIRE(grid.y < 65536 && grid.z < 65536, MISTITCH_ERR_UNSUPPORTED, "image too large for one launch");
+  MS_LAUNCH(ctx, "k_pyramid", k_pyramid, grid, dim3(256), 0, image, h, w, n_levels, lv);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }

@@ -112,6 +112,31 @@ def compute_mip(tiles):
     return out.cpu().numpy() if is_np else out
 
 
+def generate_pyramid(image, num_levels: int):
+    """[image, level 1, ..., level num_levels-1] as Stitcher.generate_pyramid builds it
+    (stitcher.py:652-668): level l is the float64 mean over 2^l x 2^l blocks of the two
+    last axes, excess rows / columns trimmed.  ``image`` is uint16 with any leading axes."""
+    import ctypes as C
+
+    torch = _torch()
+    is_np = not isinstance(image, torch.Tensor)
+    img = to_device_u16(image)
+    if img.dim() < 2:
+        raise ValueError("image must have at least two axes")
+    lead = tuple(int(v) for v in img.shape[:-2])
+    h, w = int(img.shape[-2]), int(img.shape[-1])
+    planes = int(np.prod(lead)) if lead else 1
+    levels = [torch.empty(lead + (h >> l, w >> l), dtype=torch.float64, device=img.device)
+              for l in range(1, int(num_levels))]
+    arr = (C.c_void_p * max(int(num_levels), 1))()
+    for l, t in enumerate(levels, start=1):
+        arr[l] = t.data_ptr() if t.numel() else None
+    ctx = _lib.default_context()
+    check(lib.mistitch_pyramid(ctx.handle, ptr(img), planes, h, w, int(num_levels), arr))
+    out = [img] + levels
+    return [t.cpu().numpy() for t in out] if is_np else out
+
+
 def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_w: int,
                flatfields=None, tile_ff=None, mode: str = "overwrite", rows: Optional[Tuple[int, int]] = None,
                out=None, ctx: Optional[_lib.Context] = None):

@@ -179,6 +179,15 @@ int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int til
 int mistitch_mip(mistitch_ctx* ctx, const uint16_t* in, int n, int64_t pitch, int64_t n_pixels,
                  uint16_t* out);
 
+/* Resolution pyramid of a mosaic: levels[l] (l = 1 .. n_levels-1, device pointers in
+ * a HOST array; levels[0] is ignored) receives [n_planes][h >> l][w >> l] float64, the
+ * mean of every 2^l x 2^l block, blocks that stick out of the image dropped.  All
+ * levels are produced from one read of the image.  Replaces the per-level
+ * dask.array.coarsen(np.mean, ..., trim_excess=True) of Stitcher.generate_pyramid
+ * (stitcher.py:652-668), whose levels are float64 too.  n_levels <= 7.            */
+int mistitch_pyramid(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int h, int w,
+                     int n_levels, double* const* levels);
+
 /* Per-kernel timing with HIP events recorded on the context's stream around
  * every launch (measurement aid; no counterpart in the reference).  Enable,
  * run any entry points, then collect: kernel names come back '\n'-separated in

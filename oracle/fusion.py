@@ -14,7 +14,7 @@ st:296-300): it is this project's own specification, parity unpinned.
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Sequence, Tuple
+from typing import List, Dict, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -125,4 +125,24 @@ def fuse_feather(tiles: np.ndarray, tile_yx: np.ndarray, tile_plane: Sequence[in
     covered = den > 0
     q = np.floor(num[covered] / den[covered] + np.float32(0.5))
     out[covered] = np.minimum(q, np.float32(65535.0)).astype(np.uint16)
+    return out
+
+
+# ----------------------------------------------------------------------------
+# resolution pyramid                                             st:652-668
+# ----------------------------------------------------------------------------
+def generate_pyramid(image: np.ndarray, num_levels: int) -> List[np.ndarray]:
+    """Level l = np.mean over 2^l x 2^l blocks of the last two axes of the ORIGINAL image,
+    excess trimmed: what ``da.coarsen(np.mean, image, {3: s, 4: s}, trim_excess=True)``
+    computes (dask reshapes each axis into (n // s, s) and reduces the second part);
+    the result is float64.  dask is not installed here: restated from its documented
+    behaviour, not executed."""
+    out = [image]
+    h, w = image.shape[-2:]
+    for level in range(1, num_levels):
+        s = 2 ** level
+        hh, ww = h // s, w // s
+        trimmed = image[..., :hh * s, :ww * s]
+        blocks = trimmed.reshape(image.shape[:-2] + (hh, s, ww, s))
+        out.append(np.mean(blocks, axis=(-3, -1)))
     return out

@@ -144,3 +144,18 @@ def test_mip(fu):
     assert np.array_equal(fu.compute_mip(list(stack)), ofu.compute_mip(list(stack)))
     with pytest.raises(ValueError):
         fu.compute_mip([])
+
+
+@pytest.mark.parametrize("shape,levels", [((1, 2, 1, 300, 517), 4), ((3, 64, 256), 7), ((130, 1031), 6), ((2, 7, 9), 3)])
+def test_pyramid_levels_match_block_means(shape, levels):
+    """Every level bit-exact against np.mean over 2^l blocks (float64, trimmed)."""
+    from image_stitcher_amd import fusion
+    rng = np.random.default_rng(sum(shape))
+    img = rng.integers(0, 65536, size=shape).astype(np.uint16)
+    got = fusion.generate_pyramid(img, levels)
+    want = ofu.generate_pyramid(img, levels)
+    assert len(got) == len(want) == levels
+    for l in range(levels):
+        assert got[l].shape == want[l].shape, l
+        assert got[l].dtype == want[l].dtype, l
+        assert np.array_equal(got[l], want[l]), l

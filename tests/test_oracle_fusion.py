@@ -92,3 +92,13 @@ def test_feather_self_consistency():
     assert (fea[cover == 0] == 0).all()
     const = np.full_like(tiles, 1234)
     assert (ofu.fuse_feather(const, yx, plane, 2, mh, mw)[cover > 0] == 1234).all()  # constants are preserved
+
+
+def test_pyramid_block_means_known_answer():
+    """2 x 2 and 4 x 4 block means of a ramp, trimmed, float64 (stitcher.py:652-668)."""
+    img = np.arange(5 * 9, dtype=np.uint16).reshape(1, 5, 9)
+    lv = ofu.generate_pyramid(img, 3)
+    assert [a.shape for a in lv] == [(1, 5, 9), (1, 2, 4), (1, 1, 2)]
+    assert lv[1].dtype == np.float64
+    assert lv[1][0, 0, 0] == (0 + 1 + 9 + 10) / 4 and lv[1][0, 1, 3] == (24 + 25 + 33 + 34) / 4
+    assert lv[2][0, 0, 1] == img[0, :4, 4:8].mean()
