@@ -31,7 +31,7 @@ EXPORTS = [
     "mistitch_pcm", "mistitch_pcm_topk", "mistitch_ncc", "mistitch_edge_variance",
     "mistitch_apply_flatfield", "mistitch_fuse", "mistitch_mip", "mistitch_synchronize",
     "mistitch_profile_enable", "mistitch_profile_collect", "mistitch_subpixel_shift",
-    "mistitch_set_upsample_factor", "mistitch_pyramid",
+    "mistitch_set_upsample_factor", "mistitch_pyramid", "mistitch_refine_pairs",
 ]
 
 
@@ -56,6 +56,7 @@ def _load() -> C.CDLL:
         "mistitch_set_pair_chunk": [vp, i32],
         "mistitch_reserve_registration": [vp, i32, i32, i32, i32, u32],
         "mistitch_register_pairs": [vp, vp, i32, i32, i32, i64, vp, vp, i32, i32, u32, vp, vp],
+        "mistitch_refine_pairs": [vp, vp, i32, i32, i32, i64, vp, vp, i32, i32, vp, C.c_double, vp, vp],
         "mistitch_pcm": [vp, vp, i64, vp, i64, i32, i32, u32, vp],
         "mistitch_pcm_topk": [vp, vp, i64, vp, i64, i32, i32, u32, i32, vp, vp, vp],
         "mistitch_ncc": [vp, vp, i64, vp, i64, i32, i32, vp],

@@ -1422,6 +1422,108 @@ __global__ void k_finalize(const PairDesc* desc, const int8_t* status_in, int n_
   if (best == -INFINITY) status[p] = MISTITCH_PAIR_NO_CANDIDATE;
 }
 
+// NCC of the overlap of one pair's strips under the strip-relative shift (ty, tx), computed
+// by the whole workgroup; every thread returns the value.  -inf for an empty overlap or fewer
+// than 25 pixels, as extract_overlap_subregion + ncc give (_translation_computation.py:535-657).
+__device__ double block_ncc(const PairDesc& d, int ty, int tx, unsigned long long* red /*[5 * kThreads / 64 + 1]*/) {
+  const int ay = ty < 0 ? -ty : ty, ax = tx < 0 ? -tx : tx;
+  if (ay >= d.img_h || ax >= d.img_w) return -INFINITY;
+  const unsigned long long n = (unsigned long long)(d.img_h - ay) * (unsigned long long)(d.img_w - ax);
+  if (n < 25) return -INFINITY;
+  const int ds = d.transposed ? tx : ty, dl = d.transposed ? ty : tx;
+  const int s_lo = ds > 0 ? ds : 0, s_hi = d.S + (ds < 0 ? ds : 0);
+  const int l_lo = dl > 0 ? dl : 0, l_hi = d.L + (dl < 0 ? dl : 0);
+  unsigned long long v[5];
+  moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, s_lo, s_hi, 1,
+                  l_hi - l_lo, v);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
+  }
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();  // red may still be read from the previous call
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) red[wave * 5 + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < kThreads / 64; ++w)
+      for (int i = 0; i < 5; ++i) t[i] += red[w * 5 + i];
+    const double r = ncc_from_moments(n, t[0], t[1], t[2], t[3], t[4]);
+    red[5 * kThreads / 64] = (unsigned long long)__double_as_longlong(r);
+  }
+  __syncthreads();
+  return __longlong_as_double((long long)red[5 * kThreads / 64]);
+}
+
+// Integer hill climb of the strip NCC around a start shift, one workgroup per pair:
+// find_local_max_integer_constrained driven as refine_translations drives it
+// (registration/_constrained_refinement.py:62-138, 229-295).  start and the result are
+// shifts of the second tile in the first tile's frame; row (NaN, start) where the reference
+// keeps the start (start outside its limits, start not scoring).
+__global__ __launch_bounds__(kThreads) void k_refine_pairs(const PairDesc* desc, const int8_t* status, int pair0,
+                                                           const int32_t* __restrict__ start, double r, int H, int W,
+                                                           double* out) {
+  __shared__ unsigned long long red[5 * kThreads / 64 + 1];
+  const int p = pair0 + blockIdx.x;
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  const int iy = start[2 * p], ix = start[2 * p + 1];
+  if (status[p] != MISTITCH_PAIR_OK) {
+    if (threadIdx.x == 0) {
+      out[3 * p] = nan;
+      out[3 * p + 1] = (double)iy;
+      out[3 * p + 2] = (double)ix;
+    }
+    return;
+  }
+  const PairDesc d = desc[p];
+  const double lo_y = fmax((double)(-H + 1), (double)iy - r), hi_y = fmin((double)(H - 1), (double)iy + r);
+  const double lo_x = fmax((double)(-W + 1), (double)ix - r), hi_x = fmin((double)(W - 1), (double)ix + r);
+  int y = iy, x = ix;
+  double value = nan;
+  bool ok = lo_y <= (double)iy && (double)iy <= hi_y && lo_x <= (double)ix && (double)ix <= hi_x;
+  if (ok) {
+    value = block_ncc(d, y - d.off_y, x - d.off_x, red);
+    ok = value != INFINITY && value != -INFINITY && value == value;
+    if (!ok) value = nan;
+  }
+  if (ok) {
+    double prev = -INFINITY;
+    for (int it = 0; it < 100; ++it) {
+      double best = -INFINITY;
+      int by = 0, bx = 0;
+      bool any = false;
+      for (int dy = -1; dy <= 1; ++dy) {
+        for (int dx = -1; dx <= 1; ++dx) {
+          const double ny = (double)(y + dy), nx = (double)(x + dx);
+          if (!(lo_y <= ny && ny <= hi_y && lo_x <= nx && nx <= hi_x)) continue;
+          const double v = block_ncc(d, y + dy - d.off_y, x + dx - d.off_x, red);
+          if (!any || v > best) {  // first of equal maxima, as numpy.argmax
+            best = v;
+            by = y + dy;
+            bx = x + dx;
+            any = true;
+          }
+        }
+      }
+      if (!any) break;
+      if (best <= value || fabs(best - prev) < 1e-6) break;
+      y = by;
+      x = bx;
+      prev = value;
+      value = best;
+    }
+  }
+  if (threadIdx.x == 0) {
+    out[3 * p] = value;
+    out[3 * p + 1] = (double)y;
+    out[3 * p + 2] = (double)x;
+  }
+}
+
 __global__ __launch_bounds__(kThreads) void k_ncc_single(const uint16_t* a, int64_t pa, const uint16_t* b, int64_t pb,
                                                          int h, int w, unsigned long long* acc) {
   __shared__ unsigned long long red[5 * kThreads / 64];
@@ -2211,6 +2313,43 @@ extern "C" int mistitch_pcm_topk(mistitch_ctx* ctx, const uint16_t* strip1, int6
   MS_REQUIRE(rows && cols && vals, MISTITCH_ERR_ARG, "NULL output array");
   MS_REQUIRE(k >= 1 && k <= kMaxK, MISTITCH_ERR_ARG, "k must be in [1, %d]", kMaxK);
   return single_pair_pcm(ctx, strip1, pitch1, strip2, pitch2, h, w, flags, k, nullptr, rows, cols, vals);
+}
+
+extern "C" int mistitch_refine_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
+                                     int64_t tile_pitch, const int32_t* pair_idx, const uint8_t* pair_dir, int n_pairs,
+                                     int edge_width, const int32_t* start_yx, double r, double* out, int8_t* status) {
+  MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
+  MS_REQUIRE(n_pairs >= 0 && n_tiles >= 0, MISTITCH_ERR_ARG, "negative count");
+  if (n_pairs == 0) return MISTITCH_OK;
+  MS_REQUIRE(tiles && pair_idx && pair_dir && start_yx && out && status, MISTITCH_ERR_ARG, "NULL array argument");
+  MS_REQUIRE(tile_h > 0 && tile_w > 0 && edge_width > 0, MISTITCH_ERR_ARG, "non-positive size");
+  MS_REQUIRE(tile_pitch >= (int64_t)tile_h * tile_w, MISTITCH_ERR_ARG, "tile_pitch smaller than a tile");
+  MS_REQUIRE(r >= 0.0, MISTITCH_ERR_ARG, "r must be non-negative");
+  MS_HIP(hipSetDevice(ctx->device));
+  const int H = tile_h, W = tile_w;
+  const int w_left = edge_width < W ? edge_width : W;
+  const int w_top = edge_width < H ? edge_width : H;
+  const int chunk = n_pairs < ctx->pair_chunk ? n_pairs : ctx->pair_chunk;
+  int rc;
+  if ((rc = ctx->desc.reserve((size_t)n_pairs * sizeof(PairDesc)))) return rc;
+  if ((rc = ctx->staging.reserve((size_t)chunk * w_left * H * 2 * 2 + 256))) return rc;
+  PairDesc* desc = (PairDesc*)ctx->desc.ptr;
+  uint16_t* staging = (uint16_t*)ctx->staging.ptr;
+  const bool vec_top = aligned16(tiles) && (W % 8 == 0) && (tile_pitch % 8 == 0);
+  MS_LAUNCH(ctx, "k_setup_pairs", k_setup_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, tiles, tile_pitch, H, W, w_left,
+            w_top, pair_idx, pair_dir, n_pairs, n_tiles, staging, chunk, desc, status);
+  for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {
+    const int n = std::min(chunk, n_pairs - pair0);
+    if (vec_top && H % 64 == 0 && w_left % 64 == 0)
+      MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips64, dim3(H / 64, w_left / 64, 2 * n), dim3(256), 0, tiles,
+                tile_pitch, H, W, w_left, pair_idx, desc, status, pair0);
+    else
+      MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips, dim3((H + 31) / 32, (w_left + 31) / 32, 2 * n), dim3(32, 8), 0,
+                tiles, tile_pitch, H, W, w_left, pair_idx, desc, status, pair0);
+    MS_LAUNCH(ctx, "k_refine_pairs", k_refine_pairs, dim3(n), dim3(kThreads), 0, desc, status, pair0, start_yx, r, H, W, out);
+  }
+  MS_HIP(hipGetLastError());
+  return MISTITCH_OK;
 }
 
 extern "C" int mistitch_subpixel_shift(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1, const uint16_t* strip2,

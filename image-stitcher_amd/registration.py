@@ -114,6 +114,40 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
     return out, status
 
 
+def refine_pairs(tiles, pair_idx, pair_dir, start_yx, r: float, edge_width: int = DEFAULT_EDGE_WIDTH,
+                 ctx: Optional[_lib.Context] = None):
+    """Integer hill climb of the strip NCC around ``start_yx`` for every pair: the pair loop of
+    ``refine_translations`` (registration/_constrained_refinement.py:140-307) in one device call.
+
+    start_yx [P, 2] integer shifts of the second tile in the first tile's frame (the
+    ``{left,top}_{y,x}_second`` columns of the reference's grid); r the search radius.
+    Returns (out [P, 3] float64 CUDA tensor: ncc, y, x - NaN ncc and the start shift where the
+    reference keeps its start; status [P] int8).
+    """
+    torch = _torch()
+    if not isinstance(r, (int, float)) or r < 0:
+        raise ValueError("r must be a non-negative number")
+    if not isinstance(edge_width, (int, np.integer)) or edge_width <= 0:
+        raise ValueError("edge_width must be a positive integer")
+    tiles = to_device_u16(tiles)
+    if tiles.dim() != 3:
+        raise ValueError(f"tiles must be [N, H, W], got {tuple(tiles.shape)}")
+    dev = tiles.device
+    pi = torch.as_tensor(np.asarray(pair_idx, dtype=np.int32).reshape(-1, 2)).to(device=dev).contiguous()
+    pd_ = torch.as_tensor(np.asarray(pair_dir, dtype=np.uint8).reshape(-1)).to(device=dev).contiguous()
+    st = torch.as_tensor(np.asarray(start_yx, dtype=np.int32).reshape(-1, 2)).to(device=dev).contiguous()
+    n_pairs = int(pi.shape[0])
+    if int(pd_.shape[0]) != n_pairs or int(st.shape[0]) != n_pairs:
+        raise ValueError("pair_idx, pair_dir and start_yx disagree on the number of pairs")
+    out = torch.empty((n_pairs, 3), dtype=torch.float64, device=dev)
+    status = torch.empty((n_pairs,), dtype=torch.int8, device=dev)
+    ctx = ctx or _lib.default_context()
+    n, h, w = (int(s) for s in tiles.shape)
+    check(lib.mistitch_refine_pairs(ctx.handle, ptr(tiles), n, h, w, h * w, ptr(pi), ptr(pd_), n_pairs, int(edge_width),
+                                    ptr(st), float(r), ptr(out), ptr(status)))
+    return out, status
+
+
 def compute_single_translation(image1_full: np.ndarray, image2_full: np.ndarray, direction: str,
                                full_sizeY: int, full_sizeX: int, edge_width: int,
                                fft: str = "f64") -> Optional[Tuple[float, float, float]]:

@@ -104,6 +104,22 @@ int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tile
                             const uint8_t* pair_dir, int n_pairs, int edge_width, unsigned flags,
                             double* out, int8_t* status);
 
+/* Integer hill climb of the strip NCC around given start shifts: from start_yx the
+ * best of the 3 x 3 integer neighbours (first of equal maxima, row-major) is taken
+ * while it strictly improves, within +-r of the start and the tile extent, at most
+ * 100 moves.  Replaces the pair loop of refine_translations and
+ * find_local_max_integer_constrained (registration/_constrained_refinement.py:
+ * 140-307, 62-138).  Arguments as mistitch_register_pairs, plus
+ *   start_yx   [n_pairs][2] int32: start shift of the second tile in the first tile's frame
+ *   out        [n_pairs][3] float64: ncc, y, x; (NaN, start) where the reference keeps
+ *              the start (start outside its limits or not scoring)
+ *   status     [n_pairs] int8: MISTITCH_PAIR_OK, or MISTITCH_PAIR_FEATURELESS for a pair
+ *              with a tile index out of range                                          */
+int mistitch_refine_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
+                          int64_t tile_pitch, const int32_t* pair_idx, const uint8_t* pair_dir,
+                          int n_pairs, int edge_width, const int32_t* start_yx, double r, double* out,
+                          int8_t* status);
+
 /* Subpixel shift between two equal-shape uint16 strips by upsampled DFT: the
  * coarse shift is the largest |PCM| value, refined on a ceil(1.5 u) square grid
  * of spacing 1/u.  Replaces skimage.registration.phase_cross_correlation(a, b,

@@ -221,3 +221,38 @@ def test_register_pairs_with_subpixel_candidate(reg):
     # without the flag the integer result of the discrete search is unchanged
     plain, _ = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 64)
     assert np.array_equal(np.rint(out[:, 1:]), plain.cpu().numpy()[:, 1:])
+
+
+def test_refine_pairs_matches_reference_golden(reg):
+    """The hill climb against vectors produced by the reference's refine_translations."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refine_golden.json")) as f:
+        cases = json.load(f)["cases"]
+    for spec in cases:
+        g = _grid(spec)
+        out, status = reg.refine_pairs(g.tiles, g.pair_idx, g.pair_dir, spec["start"], spec["r"], spec["edge_width"])
+        out, status = out.cpu().numpy(), status.cpu().numpy()
+        exp = np.array(spec["results"], dtype=np.float64)
+        assert (status == 0).all()
+        assert np.array_equal(out[:, 1:], exp[:, 1:]), spec["name"]
+        assert np.allclose(out[:, 0], exp[:, 0], rtol=0, atol=1e-12, equal_nan=True), spec["name"]
+
+
+def test_refine_pairs_climbs_and_falls_back(reg):
+    """Smooth scenes give the climb a slope to follow; a start outside the tile keeps its value with NaN."""
+    from oracle import refine as oref
+    rng = np.random.default_rng(9)
+    big = rng.random((300, 700))
+    k = np.fft.fftfreq(300)[:, None] ** 2 + np.fft.fftfreq(700)[None, :] ** 2
+    smooth = np.fft.ifft2(np.fft.fft2(big) * np.exp(-k * 600.0)).real
+    smooth = (1000 + 60000 * (smooth - smooth.min()) / (smooth.max() - smooth.min())).astype(np.uint16)
+    tiles = np.ascontiguousarray(np.stack([smooth[20:276, 10:266], smooth[23:279, 230:486]]))
+    pair_idx, pair_dir = [[0, 1], [0, 1]], [0, 0]
+    start = [[0, 214], [900, 5]]
+    want = oref.refine_pairs(tiles, pair_idx, pair_dir, start, 12, 64)
+    out, _ = reg.refine_pairs(tiles, pair_idx, pair_dir, start, 12, 64)
+    out = out.cpu().numpy()
+    assert np.array_equal(out[:, 1:], want[:, 1:])
+    assert np.allclose(out[:, 0], want[:, 0], rtol=0, atol=1e-12, equal_nan=True)
+    assert (out[0, 1], out[0, 2]) == (3.0, 220.0) and np.isnan(out[1, 0])
