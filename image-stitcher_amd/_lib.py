@@ -169,3 +169,13 @@ def ptr(t) -> C.c_void_p:
     if t is None:
         return C.c_void_p(0)
     return C.c_void_p(t.data_ptr())
+
+
+def ptr_of(t) -> C.c_void_p:
+    """Device pointer of a (possibly strided) tensor view's first element."""
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_at(t, i: int) -> C.c_void_p:
+    """Device pointer of element ``i`` of a contiguous 1-D tensor."""
+    return C.c_void_p(t.data_ptr() + int(i) * t.element_size())

@@ -314,3 +314,33 @@ def is_edge_featureless(edge: np.ndarray, variance_threshold: float = 2e3) -> bo
     if edge[::16, ::16].size == 0:
         return True
     return edge_variance(np.ascontiguousarray(edge)) < variance_threshold
+
+
+def select_best_registration_channel(acquisition, sample_fovs: Sequence[int],
+                                     edge_width: int = DEFAULT_EDGE_WIDTH) -> int:
+    """Channel whose right-edge strips have the largest mean 16-strided variance over the
+    sampled fields of view: the decision of select_best_registration_channel
+    (tile_registration.py:430-485) for tiles already in memory.  File discovery and the random
+    choice of fields stay with the caller; ``acquisition`` is [C, N, H, W] uint16 (tensor or
+    array), ``sample_fovs`` the tile indices to look at.  Ties go to the lowest channel, as
+    Python's max over the reference's insertion-ordered dict does."""
+    torch = _torch()
+    acq = acquisition
+    if not isinstance(acq, torch.Tensor):
+        acq = np.asarray(acq)
+    if acq.ndim != 4:
+        raise ValueError("acquisition must be [C, N, H, W]")
+    if len(sample_fovs) == 0:
+        return 0
+    n_ch, _, h, w = (int(v) for v in acq.shape)
+    cw = min(int(edge_width), w)
+    ctx = _lib.default_context()
+    means = []
+    for c in range(n_ch):
+        tiles = to_device_u16(acq[c])
+        out = torch.empty((len(sample_fovs),), dtype=torch.float64, device=tiles.device)
+        for i, t in enumerate(sample_fovs):
+            strip = tiles[int(t), :, w - cw:]
+            check(lib.mistitch_edge_variance(ctx.handle, _lib.ptr_of(strip), w, h, cw, _lib.ptr_at(out, i)))
+        means.append(float(out.mean().cpu()))
+    return int(np.argmax(means))

@@ -256,3 +256,13 @@ def test_refine_pairs_climbs_and_falls_back(reg):
     assert np.array_equal(out[:, 1:], want[:, 1:])
     assert np.allclose(out[:, 0], want[:, 0], rtol=0, atol=1e-12, equal_nan=True)
     assert (out[0, 1], out[0, 2]) == (3.0, 220.0) and np.isnan(out[1, 0])
+
+
+def test_select_best_registration_channel(reg):
+    rng = np.random.default_rng(3)
+    acq = np.stack([np.stack([(5000 + amp * rng.random((128, 160))).astype(np.uint16) for _ in range(4)])
+                    for amp in (300.0, 4000.0, 900.0)])
+    fovs = [0, 2, 3]
+    want = int(np.argmax([np.mean([np.var(acq[c, t][:, -64:][::16, ::16].astype(np.float32)) for t in fovs])
+                          for c in range(3)]))
+    assert reg.select_best_registration_channel(acq, fovs, 64) == want == 1
