@@ -131,9 +131,10 @@ struct LineAddr {
   static constexpr int kPadShift = std::is_same<T, float>::value ? 5 : 4;
   __host__ __device__ __forceinline__ static int padded(int i) { return i + (i >> kPadShift); }
   __device__ __forceinline__ int operator()(int f, int i) const { return f * fstride + padded(i); }
+  // work item w -> (transform f, butterfly g); per = butterflies per transform, a power of two
   __device__ __forceinline__ void split(int w, int nfft, int per, int& f, int& g) const {
-    f = w / per;
-    g = w - f * per;
+    f = w >> (31 - __builtin_clz(per));
+    g = w & (per - 1);
   }
 };
 
@@ -141,9 +142,10 @@ template <typename T>
 struct ColAddr {
   int rowstride;
   __device__ __forceinline__ int operator()(int f, int i) const { return i * rowstride + f; }
+  // adjacent lanes take adjacent columns; nfft (columns) must be a power of two
   __device__ __forceinline__ void split(int w, int nfft, int per, int& f, int& g) const {
-    g = w / nfft;
-    f = w - g * nfft;
+    g = w >> (31 - __builtin_clz(nfft));
+    f = w & (nfft - 1);
   }
 };
 
@@ -185,15 +187,17 @@ __device__ __forceinline__ void twiddle_powers(cx<T> base, cx<T> (&w)[R]) {
 template <typename T, int R, bool INV, class Addr>
 __device__ __forceinline__ void fft_pass(cx<T>* buf, const Addr& addr, int nfft, int N, int n,
                                          const Twiddles<T>& tw, int tid, int nthr) {
+  // every length here is a power of two: shifts, not divisions
   const int per = N / R;
   const int sub = n / R;
-  const int twstep = N / n;
+  const int lsub = 31 - __builtin_clz(sub), ln = 31 - __builtin_clz(n);
+  const int ltwstep = (31 - __builtin_clz(N)) - ln;
   for (int w = tid; w < nfft * per; w += nthr) {
     int f, g;
     addr.split(w, nfft, per, f, g);
-    const int blk = g / sub;
-    const int j = g - blk * sub;
-    const int base = blk * n + j;
+    const int blk = g >> lsub;
+    const int j = g & (sub - 1);
+    const int base = (blk << ln) + j;
     cx<T> v[R];
 #pragma unroll
     for (int m = 0; m < R; ++m) v[m] = buf[addr(f, base + m * sub)];
@@ -201,14 +205,14 @@ __device__ __forceinline__ void fft_pass(cx<T>* buf, const Addr& addr, int nfft,
       Dft<T, R, false>::run(v);
       if (sub > 1) {
         cx<T> pw[R];
-        twiddle_powers<T, R>(tw.get(j * twstep), pw);
+        twiddle_powers<T, R>(tw.get(j << ltwstep), pw);
 #pragma unroll
         for (int d = 1; d < R; ++d) v[d] = cmul(v[d], pw[d]);
       }
     } else {
       if (sub > 1) {
         cx<T> pw[R];
-        twiddle_powers<T, R>(tw.get(j * twstep), pw);
+        twiddle_powers<T, R>(tw.get(j << ltwstep), pw);
 #pragma unroll
         for (int d = 1; d < R; ++d) v[d] = cmulc(v[d], pw[d]);
       }

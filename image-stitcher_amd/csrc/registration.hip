@@ -364,6 +364,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
   MS_STAMP(0, 0);
   const Twiddles<T> tw = load_twiddles<T>(buf + NF * addr.fstride, planL, tid, kThreads);
   const int s0 = blockIdx.x * NF;
+  const int lL = 31 - __builtin_clz(L), lNF = 31 - __builtin_clz(NF);  // powers of two on this path
   if constexpr (VEC) {
     constexpr int U = 2;  // 16-byte loads of both strips in flight before the first LDS write
     for (int e0 = tid * 8; e0 < NF * L; e0 += kThreads * 8 * U) {
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
         // out-of-range lanes re-read the last group instead of branching: a branch
         // around a load makes the compiler drain the memory pipe at every join
         const int e = min(e0 + u * kThreads * 8, NF * L - 8);
-        const int f = e / L, i = e - f * L;
+        const int f = e >> lL, i = e & (L - 1);
         va[u] = *reinterpret_cast<const uint4*>(d.a + (int64_t)(s0 + f) * d.pitch + i);
         vb[u] = *reinterpret_cast<const uint4*>(d.b + (int64_t)(s0 + f) * d.pitch + i);
       }
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
       for (int u = 0; u < U; ++u) {
         const int e = e0 + u * kThreads * 8;
         if (e < NF * L) {
-          const int f = e / L, i = e - f * L;
+          const int f = e >> lL, i = e & (L - 1);
           const unsigned wa[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, wb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
@@ -398,7 +399,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
     }
   } else {
     for (int e = tid; e < NF * L; e += kThreads) {
-      const int f = e / L, i = e - f * L;
+      const int f = e >> lL, i = e & (L - 1);
       buf[addr(f, i)] = mk<T>((T)d.a[(int64_t)(s0 + f) * d.pitch + i], (T)d.b[(int64_t)(s0 + f) * d.pitch + i]);
     }
   }
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
   cx<T>* out = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L) + (int64_t)s0 * kSlab;
   const int64_t sp = slab_pitch(S);
   for (int e = tid; e < NF * L; e += kThreads) {
-    const int c8 = e % kSlab, f = (e / kSlab) % NF, slab = e / (kSlab * NF);
+    const int c8 = e % kSlab, f = (e / kSlab) & (NF - 1), slab = (e / kSlab) >> lNF;
     out[slab * sp + f * kSlab + c8] = buf[addr(f, slab * kSlab + c8)];
   }
   MS_STAMP(0, 3);
@@ -460,6 +461,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   const int64_t sp = slab_pitch(S);
   MS_STAMP(1, 0);
   const Twiddles<T> tw = load_twiddles<T>(buf + S * rs, planS, tid, kThreads);
+  const int lncol = 31 - __builtin_clz(ncol), lna = 31 - __builtin_clz(na);  // 8 or 16 columns: shifts, not divisions
   {
     constexpr int U = 16;  // loads in flight per lane before the first LDS write
     for (int e0 = tid; e0 < S * ncol; e0 += kThreads * U) {
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = min(e0 + u * kThreads, S * ncol - 1);  // clamp, do not branch around the load
-        const int s = e / ncol, c = e - s * ncol;
+        const int s = e >> lncol, c = e & (ncol - 1);
         const int pos = c < na ? un.a0 + c : un.b0 + (c - na);
         r[u] = Zs[(pos / kSlab) * sp + s * kSlab + pos % kSlab];
       }
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
       for (int u = 0; u < U; ++u) {
         const int e = e0 + u * kThreads;
         if (e < S * ncol) {
-          const int s = e / ncol, c = e - s * ncol;
+          const int s = e >> lncol, c = e & (ncol - 1);
           buf[s * rs + c] = r[u];
         }
       }
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   fft_forward<T>(buf, addr, ncol, planS, tw, tid, kThreads);
   MS_STAMP(1, 2);
   for (int e = tid; e < S * na; e += kThreads) {
-    const int q = e / na, c = e - q * na;
+    const int q = e >> lna, c = e & (na - 1);
     const int mp = planL.mpos[un.a0 + c];
     const bool partner_in_a = mp >= un.a0 && mp < un.a0 + na;
     const int pc = partner_in_a ? (mp - un.a0) : (na + mp - un.b0);
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
     // to ascending signed frequency -S/2 .. S/2-1
     cx<T>* Rs = keep_r + (int64_t)blockIdx.y * slab_pair_elems(S, L);
     for (int e = tid; e < S * na; e += kThreads) {
-      const int q = e / na, c = e - q * na;
+      const int q = e >> lna, c = e & (na - 1);
       const int pos = un.a0 + c;
       const int kk = (planS.pos2freq[q] + S / 2) & (S - 1);
       Rs[(pos / kSlab) * sp + kk * kSlab + pos % kSlab] = buf[q * rs + c];
@@ -529,7 +531,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   fft_inverse<T>(buf, addr, na, planS, tw, tid, kThreads);
   MS_STAMP(1, 4);
   for (int e = tid; e < S * na; e += kThreads) {
-    const int s = e / na, c = e - s * na;
+    const int s = e >> lna, c = e & (na - 1);
     Z[(int64_t)s * Lp + un.a0 + c] = buf[s * rs + c];
   }
   MS_STAMP(1, 5);
@@ -556,6 +558,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   LineAddr<T> addr{LineAddr<T>::padded(L) + 1};
   const Twiddles<T> tw = load_twiddles<T>(buf + NF * addr.fstride, planL, tid, kThreads);
   const int s0 = blockIdx.x * NF * 2;
+  const int lL = 31 - __builtin_clz(L);  // a power of two on this path
   const int Lp = spectrum_pitch<T>(L);
   const cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
   MS_STAMP(2, 0);
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = min(e0 + u * kThreads, NF * n_stored - 1);  // clamp, do not branch around the loads
-        const int f = e / n_stored, i = e - f * n_stored;
+        const int f = NF == 1 ? 0 : e / n_stored, i = e - f * n_stored;
         const int pos = stored_pos[i];
         g1[u] = Z[(int64_t)(s0 + 2 * f) * Lp + pos];
         g2[u] = Z[(int64_t)(s0 + 2 * f + 1) * Lp + pos];
@@ -582,7 +585,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       for (int u = 0; u < U; ++u) {
         const int e = e0 + u * kThreads;
         if (e < NF * n_stored) {
-          const int f = e / n_stored, i = e - f * n_stored;
+          const int f = NF == 1 ? 0 : e / n_stored, i = e - f * n_stored;
           const int pos = stored_pos[i], mir = mirror_fill[i];
           buf[addr(f, pos)] = mk<T>(g1[u].x - g2[u].y, g1[u].y + g2[u].x);  // g1 + i g2
           if (mir != 0xffff) buf[addr(f, mir)] = mk<T>(g1[u].x + g2[u].y, g2[u].x - g1[u].y);  // conj(g1) + i conj(g2)
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   if (pcm_out != nullptr) {
     double* out = pcm_out + (int64_t)blockIdx.y * S * L;
     for (int e = tid; e < NF * L; e += kThreads) {
-      const int f = e / L, l = e - f * L;
+      const int f = e >> lL, l = e & (L - 1);
       const cx<T> v = buf[addr(f, l)];
       const int s = s0 + 2 * f;
       if (d.transposed) {
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
     Peak b1{-INFINITY, -1, -1}, b2{-INFINITY, -1, -1};
     Peak ba{-INFINITY, -1, -1};  // largest magnitude, first in row-major order (subpixel stage only)
     for (int e = tid; e < NF * L; e += kThreads) {
-      const int f = e / L, l = e - f * L;
+      const int f = e >> lL, l = e & (L - 1);
       const int a0 = addr(f, l);
       const cx<T> v = buf[a0];
       const int s = s0 + 2 * f;
