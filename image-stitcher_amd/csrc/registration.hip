@@ -984,30 +984,17 @@ struct KappaEntry {
   int8_t self;      // 1: the column is its own conjugate partner (kappa = 0 or L / 2)
 };
 
-// X_b for one whole slab (8 columns): every lane of the workgroup needs the same spectrum
-// values, so they are read through the scalar cache (constant address space, one 128-byte
-// row per step) and enter the multiply-adds as scalar operands; LDS broadcasts of the same
-// values ran four times slower.
-template <typename T>
-__device__ __forceinline__ void ups_short_slab(const cx<T>* slab, int S, double2 w, double2 step, double2 (&acc)[kSlab]) {
-  typedef const __attribute__((address_space(4))) T* scalar_ptr;
-  scalar_ptr rows = (scalar_ptr)(unsigned long long)slab;
-#pragma unroll
-  for (int c = 0; c < kSlab; ++c) acc[c] = mk<double>(0.0, 0.0);
-  for (int kk = 0; kk < S; ++kk) {
-    scalar_ptr row = rows + kk * (2 * kSlab);
-#pragma unroll
-    for (int c = 0; c < kSlab; ++c) {
-      const double rx = (double)row[2 * c], ry = (double)row[2 * c + 1];
-      acc[c].x += rx * w.x - ry * w.y;
-      acc[c].y += rx * w.y + ry * w.x;
-    }
-    w = cmul(w, step);
-  }
-}
+// First stage on the matrix cores.  For one slab (8 columns) X[u][c] = sum_kk R[kk][c] E[u][kk],
+// E[u][kk] = exp(i theta_u (kk - S/2)), is a real product C = A B with
+//   A[u][2 kk + p]       = p ? Im E : Re E                       (generated: one rotor per lane)
+//   B[2 kk + p][2 c + o] = (p == o) ? Re R : (p ? -Im R : Im R)  (one double per lane from LDS)
+//   C[u][2 c + o]        = o ? Im X : Re X
+// run as v_mfma_f64_16x16x4_f64 steps: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15];
+// result register g of lane l is C[(l >> 4) + 4 g][l & 15].  A step covers two kk.
+// grid (n_units, pairs_in_pass); a wave owns up to kUpsTilesPerWave 16-row tiles of u.
+constexpr int kUpsTilesPerWave = 3;  // 4 waves x 3 tiles x 16 rows >= kUpsMax
+typedef double d4 __attribute__((ext_vector_type(4)));
 
-// grid (n_units, pairs_in_pass); threads 0 .. n_up-1 own one displacement each.  The rows
-// of `rslabs` are in ascending signed frequency (k_fft_short_cps wrote them so).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, const int8_t* status, int pair0, int S,
                                                         int L, int want_transposed, FftPlanDev planS,
@@ -1016,6 +1003,8 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
                                                         const cx<T>* __restrict__ rslabs,
                                                         const UpsState* __restrict__ ups, int n_up, double uf,
                                                         double2* __restrict__ T1, double2* __restrict__ Nq) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* rows = reinterpret_cast<double*>(smem_raw);  // [S][2 * kSlab]: one slab, rows in ascending signed frequency
   const int p = pair0 + blockIdx.y;
   if (status[p] != MISTITCH_PAIR_OK) return;
   {
@@ -1025,7 +1014,7 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
   const UpsState st = ups[p];
   if (!st.valid) return;
   const CpsUnit un = units[blockIdx.x];
-  const int na = un.na, tid = threadIdx.x;
+  const int na = un.na, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const cx<T>* Rs = rslabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
   const int64_t sp = slab_pitch(S);
   if (tid < na) {  // the Nyquist row (signed frequency -S/2, the first row) of every column
@@ -1033,34 +1022,80 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
     const cx<T> v = Rs[(pos / kSlab) * sp + pos % kSlab];
     Nq[(int64_t)blockIdx.y * n_stored + pos2stored[pos]] = mk<double>((double)v.x, (double)v.y);
   }
-  if (tid >= n_up) return;
-  const double delta = (double)st.shift_s + ((double)tid - (double)(n_up / 2)) / uf;
-  const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
-  double sn, cs;
-  sincos(theta, &sn, &cs);
-  const double2 step = mk<double>(cs, sn);
-  sincos(theta * (double)(-(S / 2)), &sn, &cs);
-  const double2 w = mk<double>(cs, sn);  // exp(i theta k), k = -S/2 first
-  double2* out = T1 + ((int64_t)blockIdx.y * n_up + tid) * n_stored;
+  double2* t1 = T1 + (int64_t)blockIdx.y * n_up * n_stored;
+  // lane roles inside a step
+  const int i = lane & 15, k = lane >> 4;  // A: row i, k index; B: k index, column i
+  const int part = k & 1, kk_off = k >> 1;
+  const int comp = (part != (i & 1)) ? 1 : 0;            // which component of R this lane feeds to B
+  const double bsign = (part == 1 && (i & 1) == 0) ? -1.0 : 1.0;
+  const int bcol = 2 * (i >> 1) + comp;
   int pos = un.a0;
   const int end = un.a0 + na;
   while (pos < end) {
-    if (pos % kSlab == 0 && pos + kSlab <= end) {
-      double2 acc[kSlab];
-      ups_short_slab<T>(Rs + (pos / kSlab) * sp, S, w, step, acc);
-#pragma unroll
-      for (int c = 0; c < kSlab; ++c) out[pos2stored[pos + c]] = acc[c];
-      pos += kSlab;
-    } else {  // a unit narrower than a slab: one column at a time
-      const cx<T>* col = Rs + (pos / kSlab) * sp + pos % kSlab;
-      double2 acc = mk<double>(0.0, 0.0), ww = w;
-      for (int kk = 0; kk < S; ++kk) {
-        const cx<T> r = col[kk * kSlab];
-        acc.x += (double)r.x * ww.x - (double)r.y * ww.y;
-        acc.y += (double)r.x * ww.y + (double)r.y * ww.x;
-        ww = cmul(ww, step);
+    if (pos % kSlab == 0 && pos + kSlab <= end && (S & 1) == 0) {
+      __syncthreads();  // the previous slab has been consumed
+      const cx<T>* slab = Rs + (pos / kSlab) * sp;
+      for (int e = tid; e < S * kSlab; e += kThreads) {
+        const cx<T> v = slab[e];
+        rows[2 * e] = (double)v.x;
+        rows[2 * e + 1] = (double)v.y;
       }
-      out[pos2stored[pos]] = acc;
+      __syncthreads();
+      d4 acc[kUpsTilesPerWave];
+      double2 w[kUpsTilesPerWave], step2[kUpsTilesPerWave];
+#pragma unroll
+      for (int t = 0; t < kUpsTilesPerWave; ++t) {
+        acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        const int u = (wave * kUpsTilesPerWave + t) * 16 + i;
+        const double delta = (double)st.shift_s + ((double)u - (double)(n_up / 2)) / uf;
+        const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
+        double sn, cs;
+        sincos(theta * (double)(kk_off - S / 2), &sn, &cs);
+        w[t] = mk<double>(cs, sn);
+        sincos(2.0 * theta, &sn, &cs);
+        step2[t] = mk<double>(cs, sn);
+      }
+      for (int kk0 = 0; kk0 < S; kk0 += 2) {
+        const double bv = bsign * rows[(kk0 + kk_off) * (2 * kSlab) + bcol];
+#pragma unroll
+        for (int t = 0; t < kUpsTilesPerWave; ++t) {  // tiles past n_up are computed too (branch-free) and not stored
+          const double av = part ? w[t].y : w[t].x;
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+          w[t] = cmul(w[t], step2[t]);
+        }
+      }
+      const int c = i >> 1, o = i & 1;
+      const int col = pos2stored[pos + c];
+#pragma unroll
+      for (int t = 0; t < kUpsTilesPerWave; ++t) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int u = (wave * kUpsTilesPerWave + t) * 16 + k + 4 * g;
+          if (u < n_up) {
+            double* dst = reinterpret_cast<double*>(t1 + (int64_t)u * n_stored + col);
+            dst[o] = acc[t][g];
+          }
+        }
+      }
+      pos += kSlab;
+    } else {  // a unit narrower than a slab: one column at a time on the vector units
+      if (tid < n_up) {
+        const double delta = (double)st.shift_s + ((double)tid - (double)(n_up / 2)) / uf;
+        const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
+        double sn, cs;
+        sincos(theta, &sn, &cs);
+        const double2 step = mk<double>(cs, sn);
+        sincos(theta * (double)(-(S / 2)), &sn, &cs);
+        double2 ww = mk<double>(cs, sn), acc = mk<double>(0.0, 0.0);
+        const cx<T>* col = Rs + (pos / kSlab) * sp + pos % kSlab;
+        for (int kk = 0; kk < S; ++kk) {
+          const cx<T> r = col[kk * kSlab];
+          acc.x += (double)r.x * ww.x - (double)r.y * ww.y;
+          acc.y += (double)r.x * ww.y + (double)r.y * ww.x;
+          ww = cmul(ww, step);
+        }
+        t1[(int64_t)tid * n_stored + pos2stored[pos]] = acc;
+      }
       pos += 1;
     }
   }
@@ -2065,7 +2100,9 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
     MS_REQUIRE(k >= 1 && k <= 2, MISTITCH_ERR_UNSUPPORTED, "the subpixel stage needs the two-peak search");
     MS_LAUNCH(ctx, "k_ups_coarse", k_ups_coarse, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S, cfg.L,
               want_transposed, ws.partial_abs, ws.abs_stride, nblk, ws.ups);
-    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T>), dim3(cfg.n_units, n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S,
+    const size_t lds_ups = (size_t)cfg.S * 2 * kSlab * sizeof(double);
+    if ((rc = allow_lds(ctx, k_ups_short<T>, lds_ups))) return rc;
+    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T>), dim3(cfg.n_units, n), dim3(kThreads), lds_ups, ws.desc, status, pair0, cfg.S,
               cfg.L, want_transposed, cfg.planS, cfg.units, cfg.pos2stored, ws.n_stored_max, slabs, ws.ups, ws.n_up, ws.uf,
               ws.t1, ws.nq);
     MS_LAUNCH(ctx, "k_ups_long", k_ups_long, dim3(ws.n_row_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S, cfg.L,
