@@ -50,7 +50,8 @@ def parse_args():
     ap.add_argument("--fuse-mode", default="feather", choices=["feather", "overwrite"])
     ap.add_argument("--edge-width", type=int, default=None)
     ap.add_argument("--pair-chunk", type=int, default=None)
-    ap.add_argument("--cpu-pairs", type=int, default=40, help="pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-pairs", type=int, default=220,
+                    help="pairs in the CPU baseline sample: about 12 s of single-core NumPy (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side figures (other fusion mode, other FFT precision): profiler runs")
