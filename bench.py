@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--cpu-pairs", type=int, default=220,
                     help="pairs in the CPU baseline sample: about 12 s of single-core NumPy (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on device 0 (not a measurement)")
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side figures (other fusion mode, other FFT precision): profiler runs")
     return ap.parse_args()
@@ -148,9 +150,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.rehearse_gloo:
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU; there is no CPU path"

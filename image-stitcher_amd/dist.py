@@ -76,12 +76,16 @@ def all_gather_pair_results(out, status, counts: Sequence[int]):
     pad_st[:n] = status
     all_out = torch.empty((world, pmax, 3), dtype=torch.float64, device=out.device)
     all_st = torch.empty((world, pmax), dtype=torch.int8, device=out.device)
-    if out.is_cuda:
+    if dist.get_backend() == "nccl":  # RCCL: one flat collective each, on the device
         dist.all_gather_into_tensor(all_out, pad_out)
         dist.all_gather_into_tensor(all_st, pad_st)
-    else:  # gloo has no flat-tensor variant
-        dist.all_gather(list(all_out.unbind(0)), pad_out)
-        dist.all_gather(list(all_st.unbind(0)), pad_st)
+    else:  # gloo (CPU tests, single-GPU rehearsals): list variant on host copies
+        parts_out = [torch.empty((pmax, 3), dtype=torch.float64) for _ in range(world)]
+        parts_st = [torch.empty((pmax,), dtype=torch.int8) for _ in range(world)]
+        dist.all_gather(parts_out, pad_out.cpu())
+        dist.all_gather(parts_st, pad_st.cpu())
+        all_out = torch.stack(parts_out).to(out.device)
+        all_st = torch.stack(parts_st).to(out.device)
     rows = torch.cat([all_out[r, : int(counts[r])] for r in range(world)])
     st = torch.cat([all_st[r, : int(counts[r])] for r in range(world)])
     return rows, st
