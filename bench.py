@@ -200,39 +200,35 @@ def main():
     if cfg["flatfield"]:
         ffs = torch.as_tensor(np.stack([synth.make_flatfield(tile, tile, amplitude=0.2 - 0.03 * c) for c in range(ch)]),
                               device=device)
-        reg_tiles = torch.empty((n_tiles, tile, tile), dtype=torch.int16, device=device).view(torch.uint16)
     ff_type = _lib.FF_F32 if ffs is not None else _lib.FF_NONE
     counts = [n_pairs] * world
     gathered = None
 
+    def register(flags, out, status):
+        """Flatfield-correct the registration channel and register every pair: with a flatfield the
+        strips are corrected as they are extracted (one call), which equals correcting whole tiles first."""
+        if ffs is not None:
+            check(lib.mistitch_register_pairs_flatfield(ctx.handle, ptr(tiles[0]), n_tiles, tile, tile, tile * tile,
+                                                        ptr(ffs[0]), ff_type, ptr(d_pair_idx), ptr(d_pair_dir),
+                                                        n_pairs, edge, flags, ptr(out), ptr(status)))
+        else:
+            check(lib.mistitch_register_pairs(ctx.handle, ptr(tiles[0]), n_tiles, tile, tile, tile * tile,
+                                              ptr(d_pair_idx), ptr(d_pair_dir), n_pairs, edge, flags,
+                                              ptr(out), ptr(status)))
+
     def step_registration():
         nonlocal gathered
-        if ffs is not None:
-            check(lib.mistitch_apply_flatfield(ctx.handle, ptr(tiles[0]), ptr(ffs[0]), ff_type, ptr(reg_tiles),
-                                               n_tiles, tile, tile))
-        check(lib.mistitch_register_pairs(ctx.handle, ptr(reg_tiles), n_tiles, tile, tile, tile * tile,
-                                          ptr(d_pair_idx), ptr(d_pair_dir), n_pairs, edge, fft_flag,
-                                          ptr(d_out), ptr(d_status)))
+        register(fft_flag, d_out, d_status)
         if world > 1:
             gathered = mdist.all_gather_pair_results(d_out, d_status, counts)
 
     def step_registration_other():
         """The same step at the other FFT precision (reported beside the headline figure)."""
-        if ffs is not None:
-            check(lib.mistitch_apply_flatfield(ctx.handle, ptr(tiles[0]), ptr(ffs[0]), ff_type, ptr(reg_tiles),
-                                               n_tiles, tile, tile))
-        check(lib.mistitch_register_pairs(ctx.handle, ptr(reg_tiles), n_tiles, tile, tile, tile * tile,
-                                          ptr(d_pair_idx), ptr(d_pair_dir), n_pairs, edge, other_fft_flag,
-                                          ptr(d_out2), ptr(d_status2)))
+        register(other_fft_flag, d_out2, d_status2)
 
     def step_registration_subpixel():
         """The configured step with the upsampled-DFT estimate added for every pair."""
-        if ffs is not None:
-            check(lib.mistitch_apply_flatfield(ctx.handle, ptr(tiles[0]), ptr(ffs[0]), ff_type, ptr(reg_tiles),
-                                               n_tiles, tile, tile))
-        check(lib.mistitch_register_pairs(ctx.handle, ptr(reg_tiles), n_tiles, tile, tile, tile * tile,
-                                          ptr(d_pair_idx), ptr(d_pair_dir), n_pairs, edge, fft_flag | _lib.REG_SUBPIXEL,
-                                          ptr(d_out2), ptr(d_status2)))
+        register(fft_flag | _lib.REG_SUBPIXEL, d_out2, d_status2)
 
     def fuse(mode):
         check(lib.mistitch_fuse(ctx.handle, ptr(tiles), ch * n_tiles, tile, tile, tile * tile, ptr(d_yx), ptr(d_plane),
@@ -325,6 +321,7 @@ def main():
         "k_ncc_accumulate": n_pairs * 2 * strip_px * 2,
         "k_transpose_strips": int((pair_dir == 0).sum()) * 2 * strip_px * 2 * 2,
         "k_flatfield": n_tiles * tile * tile * 4 + tile * tile * 4,
+        "k_stage_strips": n_pairs * 2 * strip_px * 4 + tile * tile * 4,   # strip pixels in and out, one flatfield plane
         "k_fuse_feather": fuse_bytes_by_mode["feather"], "k_fuse_overwrite": fuse_bytes_by_mode["overwrite"],
     }
     traffic = load_pmc_traffic(args.workload, args.fft)
@@ -372,7 +369,7 @@ def main():
                        "pairs_per_gpu": n_pairs, "edge_width": edge, "fft": args.fft,
                        "fuse_mode": args.fuse_mode, "mosaic": [ch, mosaic_h, mosaic_w]},
             "registration": {"ms_per_step": round(1e3 * t_reg / args.steps, 3),
-                             "includes": ("flatfield of the registration channel, " if ffs is not None else "")
+                             "includes": ("flatfield applied to the edge strips as they are extracted, " if ffs is not None else "")
                              + "register_pairs" + (", RCCL all-gather of pair rows" if world > 1 else ""),
                              "roofline_whole_path": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                                      "achieved": round(pairs_per_s / world * reg_bytes_per_pair / 1e9, 1),

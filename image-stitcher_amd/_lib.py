@@ -32,6 +32,7 @@ EXPORTS = [
     "mistitch_apply_flatfield", "mistitch_fuse", "mistitch_mip", "mistitch_synchronize",
     "mistitch_profile_enable", "mistitch_profile_collect", "mistitch_subpixel_shift",
     "mistitch_set_upsample_factor", "mistitch_pyramid", "mistitch_refine_pairs",
+    "mistitch_register_pairs_flatfield",
 ]
 
 
@@ -56,6 +57,7 @@ def _load() -> C.CDLL:
         "mistitch_set_pair_chunk": [vp, i32],
         "mistitch_reserve_registration": [vp, i32, i32, i32, i32, u32],
         "mistitch_register_pairs": [vp, vp, i32, i32, i32, i64, vp, vp, i32, i32, u32, vp, vp],
+        "mistitch_register_pairs_flatfield": [vp, vp, i32, i32, i32, i64, vp, i32, vp, vp, i32, i32, u32, vp, vp],
         "mistitch_refine_pairs": [vp, vp, i32, i32, i32, i64, vp, vp, i32, i32, vp, C.c_double, vp, vp],
         "mistitch_pcm": [vp, vp, i64, vp, i64, i32, i32, u32, vp],
         "mistitch_pcm_topk": [vp, vp, i64, vp, i64, i32, i32, u32, i32, vp, vp, vp],

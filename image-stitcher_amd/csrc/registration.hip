@@ -162,7 +162,7 @@ __device__ __forceinline__ Peak block_argmax_first(Peak mine, Peak* red /*[kThre
 __global__ void k_setup_pairs(const uint16_t* tiles, int64_t tile_pitch, int H, int W, int w_left,
                               int w_top, const int32_t* pair_idx, const uint8_t* pair_dir, int n_pairs,
                               int n_tiles, uint16_t* staging, int pair_chunk, PairDesc* desc,
-                              int8_t* status) {
+                              int8_t* status, int64_t slot_elems, int stage_top) {
   int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_pairs) return;
   int i1 = pair_idx[2 * p], i2 = pair_idx[2 * p + 1];
@@ -176,7 +176,7 @@ __global__ void k_setup_pairs(const uint16_t* tiles, int64_t tile_pitch, int H, 
   const uint16_t* t2 = tiles + (int64_t)i2 * tile_pitch;
   if (pair_dir[p] == 0) {  // left: last w columns of t1 against first w columns of t2
     int slot = p % pair_chunk;
-    uint16_t* st_a = staging + (int64_t)slot * 2 * w_left * H;
+    uint16_t* st_a = staging + (int64_t)slot * slot_elems;
     d.a = st_a;
     d.b = st_a + (int64_t)w_left * H;
     d.pitch = H;
@@ -190,6 +190,11 @@ __global__ void k_setup_pairs(const uint16_t* tiles, int64_t tile_pitch, int H, 
   } else {  // top: last w rows of t1 against first w rows of t2
     d.a = t1 + (int64_t)(H - w_top) * W;
     d.b = t2;
+    if (stage_top) {  // flatfield-corrected copies in the staging buffer
+      uint16_t* st_a = staging + (int64_t)(p % pair_chunk) * slot_elems;
+      d.a = st_a;
+      d.b = st_a + (int64_t)w_top * W;
+    }
     d.pitch = W;
     d.S = w_top;
     d.L = W;
@@ -330,6 +335,126 @@ __global__ __launch_bounds__(256) void k_transpose_strips64(const uint16_t* tile
     o.w = w4[3];
     *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + s) * H + l0 + 8 * sub) = o;
   }
+}
+
+// trunc(clip(v / ff)) for one pixel (tile_registration.py:2142-2181); FF as in mistitch.h.
+template <int FF>
+__device__ __forceinline__ unsigned ff_corrected(unsigned v, const void* ff, int64_t idx) {
+  if constexpr (FF == MISTITCH_FF_F32) {
+    const float q = __fdiv_rn((float)v, reinterpret_cast<const float*>(ff)[idx]);
+    return (unsigned)fminf(fmaxf(q, 0.0f), 65535.0f);
+  } else {
+    const double q = (double)v / reinterpret_cast<const double*>(ff)[idx];
+    return (unsigned)fmin(fmax(q, 0.0), 65535.0);
+  }
+}
+
+// Strip extraction with the flatfield applied on the way: both strips of every pair go to
+// the staging buffer in canonical [S][L] layout (left strips transposed), corrected as
+// load_batch_images corrects whole tiles before the reference cuts its edges
+// (tile_registration.py:2184-2279).  Only a quarter of the pixels of a tile lie in strips.
+// Sides multiples of 64, 16-byte aligned rows.  grid (max L / 64, max S / 64, 2 * pairs_in_pass).
+template <int FF>
+__global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, int64_t tile_pitch, int H, int W,
+                                                        int w_left, int w_top, const int32_t* pair_idx,
+                                                        const PairDesc* desc, const int8_t* status, int pair0,
+                                                        const void* __restrict__ ff) {
+  __shared__ uint16_t tile[64][64 + 2];
+  const int p = pair0 + (blockIdx.z >> 1), which = blockIdx.z & 1;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  const int l0 = blockIdx.x * 64, s0 = blockIdx.y * 64;
+  if (l0 >= d.L || s0 >= d.S) return;
+  const uint16_t* img = tiles + (int64_t)pair_idx[2 * p + which] * tile_pitch;
+  uint16_t* dst = const_cast<uint16_t*>(which == 0 ? d.a : d.b);
+  const int t = threadIdx.x, sub = t & 7, row = t >> 3;  // 8 lanes cover one 128-byte row segment
+  if (d.transposed) {
+    // image rows l0 .. l0+63, image columns x0 + s0 .. +63
+    const int x0 = (which == 0 ? W - w_left : 0) + s0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int y = l0 + row + 32 * i;
+      const int64_t at = (int64_t)y * W + x0 + 8 * sub;
+      const uint4 v = *reinterpret_cast<const uint4*>(img + at);
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+      unsigned* dstw = reinterpret_cast<unsigned*>(&tile[row + 32 * i][8 * sub]);  // rows are 132 bytes: 4-byte aligned
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        dstw[q] = ff_corrected<FF>(w4[q] & 0xffffu, ff, at + 2 * q) | (ff_corrected<FF>(w4[q] >> 16, ff, at + 2 * q + 1) << 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int sline = row + 32 * i;  // output line
+      uint4 o;
+      unsigned w4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        w4[q] = (unsigned)tile[8 * sub + 2 * q][sline] | ((unsigned)tile[8 * sub + 2 * q + 1][sline] << 16);
+      o.x = w4[0];
+      o.y = w4[1];
+      o.z = w4[2];
+      o.w = w4[3];
+      *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + sline) * H + l0 + 8 * sub) = o;
+    }
+  } else {
+    const int y0 = (which == 0 ? H - w_top : 0) + s0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int sline = row + 32 * i;
+      const int64_t at = (int64_t)(y0 + sline) * W + l0 + 8 * sub;
+      const uint4 v = *reinterpret_cast<const uint4*>(img + at);
+      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+      uint4 o;
+      unsigned r4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        r4[q] = ff_corrected<FF>(w4[q] & 0xffffu, ff, at + 2 * q) | (ff_corrected<FF>(w4[q] >> 16, ff, at + 2 * q + 1) << 16);
+      o.x = r4[0];
+      o.y = r4[1];
+      o.z = r4[2];
+      o.w = r4[3];
+      *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + sline) * W + l0 + 8 * sub) = o;
+    }
+  }
+}
+
+// The same for any strip size: one pixel per thread step.  grid (blocks, 2 * pairs_in_pass).
+template <int FF>
+__global__ __launch_bounds__(256) void k_stage_strips_any(const uint16_t* tiles, int64_t tile_pitch, int H, int W,
+                                                          int w_left, int w_top, const int32_t* pair_idx,
+                                                          const PairDesc* desc, const int8_t* status, int pair0,
+                                                          const void* __restrict__ ff) {
+  const int p = pair0 + (blockIdx.y >> 1), which = blockIdx.y & 1;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  const uint16_t* img = tiles + (int64_t)pair_idx[2 * p + which] * tile_pitch;
+  uint16_t* dst = const_cast<uint16_t*>(which == 0 ? d.a : d.b);
+  const int64_t n = (int64_t)d.S * d.L;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const int sline = (int)(e / d.L), l = (int)(e - (int64_t)sline * d.L);
+    int y, x;
+    if (d.transposed) {
+      y = l;
+      x = (which == 0 ? W - w_left : 0) + sline;
+    } else {
+      y = (which == 0 ? H - w_top : 0) + sline;
+      x = l;
+    }
+    const int64_t at = (int64_t)y * W + x;
+    dst[e] = (uint16_t)ff_corrected<FF>(img[at], ff, at);
+  }
+}
+
+// The featureless test on staged (canonical) strips.  grid (2, pairs_in_pass).
+__global__ void k_edge_stats_staged(const PairDesc* desc, int8_t* status, int pair0, double threshold) {
+  __shared__ unsigned long long red[2 * kThreads / 64];
+  const int p = pair0 + blockIdx.y, which = blockIdx.x;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  // every 16th sample in both directions: the same set in canonical and in image orientation
+  const double var = sampled_variance(which == 0 ? d.a : d.b, d.pitch, d.S, d.L, red);
+  if (threadIdx.x == 0 && var < threshold) status[p] = MISTITCH_PAIR_FEATURELESS;
 }
 
 // Generic transposing copy used by the single-strip entry points (tall strips).
@@ -2182,10 +2307,11 @@ extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int 
   return reserve_registration(ctx, max_pairs, chunk, (size_t)w_left * tile_h * 2, spec, slab, pstride, &ws);
 }
 
-extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h,
-                                       int tile_w, int64_t tile_pitch, const int32_t* pair_idx,
-                                       const uint8_t* pair_dir, int n_pairs, int edge_width, unsigned flags,
-                                       double* out, int8_t* status) {
+// Body of mistitch_register_pairs / mistitch_register_pairs_flatfield (ff = NULL: tiles are used as they are).
+static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
+                               int64_t tile_pitch, const void* ff, int ff_type, const int32_t* pair_idx,
+                               const uint8_t* pair_dir, int n_pairs, int edge_width, unsigned flags, double* out,
+                               int8_t* status) {
   MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
   MS_REQUIRE(n_pairs >= 0 && n_tiles >= 0, MISTITCH_ERR_ARG, "negative count");
   if (n_pairs == 0) return MISTITCH_OK;
@@ -2207,7 +2333,10 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
   const int chunk = n_pairs < ctx->pair_chunk ? n_pairs : ctx->pair_chunk;
   RegWorkspace ws;
   const size_t slab = std::max(cfg_left.slab_bytes, cfg_top.slab_bytes);
-  if ((rc = reserve_registration(ctx, n_pairs, chunk, (size_t)w_left * H * 2, spec, slab, pstride, &ws))) return rc;
+  // staging slot of a pair: its two strips; with a flatfield the top strips are staged as well
+  const int64_t slot_elems =
+      2 * (ff != nullptr ? std::max((int64_t)w_left * H, (int64_t)w_top * W) : (int64_t)w_left * H);
+  if ((rc = reserve_registration(ctx, n_pairs, chunk, (size_t)slot_elems, spec, slab, pstride, &ws))) return rc;
   const bool subpixel = (flags & MISTITCH_REG_SUBPIXEL) != 0;
   if (subpixel) {
     MS_REQUIRE(!cfg_left.general && !cfg_top.general, MISTITCH_ERR_UNSUPPORTED,
@@ -2221,23 +2350,49 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
   const int k = 2;  // peaks the candidate search consumes
 
   MS_LAUNCH(ctx, "k_setup_pairs", k_setup_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, tiles, tile_pitch, H, W, w_left,
-                     w_top, pair_idx, pair_dir, n_pairs, n_tiles, ws.staging, chunk, ws.desc, status);
-  MS_LAUNCH(ctx, "k_edge_stats", k_edge_stats, dim3(2, n_pairs), dim3(kThreads), 0, tiles, tile_pitch, H, W, w_left, w_top,
-                     pair_idx, pair_dir, status, 2e3);
+                     w_top, pair_idx, pair_dir, n_pairs, n_tiles, ws.staging, chunk, ws.desc, status, slot_elems,
+                     ff != nullptr ? 1 : 0);
+  if (ff == nullptr)
+    MS_LAUNCH(ctx, "k_edge_stats", k_edge_stats, dim3(2, n_pairs), dim3(kThreads), 0, tiles, tile_pitch, H, W, w_left, w_top,
+              pair_idx, pair_dir, status, 2e3);
   for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {
     const int n = std::min(chunk, n_pairs - pair0);
-    if (vec_top && H % 64 == 0 && w_left % 64 == 0)
+    bool vec_strips = vec_top;  // may the top strips be read with 16-byte loads
+    if (ff != nullptr) {
+      // corrected strips of both directions go to the staging buffer; the featureless test reads them there
+      const bool fast = vec_top && H % 64 == 0 && W % 64 == 0 && w_left % 64 == 0 && w_top % 64 == 0;
+      if (fast) {
+        const dim3 grid(std::max(H, W) / 64, std::max(w_left, w_top) / 64, 2 * n);
+        if (ff_type == MISTITCH_FF_F32)
+          MS_LAUNCH(ctx, "k_stage_strips", k_stage_strips64<MISTITCH_FF_F32>, grid, dim3(256), 0, tiles, tile_pitch, H, W, w_left,
+                    w_top, pair_idx, ws.desc, status, pair0, ff);
+        else
+          MS_LAUNCH(ctx, "k_stage_strips", k_stage_strips64<MISTITCH_FF_F64>, grid, dim3(256), 0, tiles, tile_pitch, H, W, w_left,
+                    w_top, pair_idx, ws.desc, status, pair0, ff);
+      } else {
+        const dim3 grid(256, 2 * n);
+        if (ff_type == MISTITCH_FF_F32)
+          MS_LAUNCH(ctx, "k_stage_strips", k_stage_strips_any<MISTITCH_FF_F32>, grid, dim3(256), 0, tiles, tile_pitch, H, W,
+                    w_left, w_top, pair_idx, ws.desc, status, pair0, ff);
+        else
+          MS_LAUNCH(ctx, "k_stage_strips", k_stage_strips_any<MISTITCH_FF_F64>, grid, dim3(256), 0, tiles, tile_pitch, H, W,
+                    w_left, w_top, pair_idx, ws.desc, status, pair0, ff);
+      }
+      MS_LAUNCH(ctx, "k_edge_stats", k_edge_stats_staged, dim3(2, n), dim3(kThreads), 0, ws.desc, status, pair0, 2e3);
+      vec_strips = aligned16(ws.staging) && (W % 8 == 0) && (slot_elems % 8 == 0) && (((int64_t)w_top * W) % 8 == 0);
+    } else if (vec_top && H % 64 == 0 && w_left % 64 == 0) {
       MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips64, dim3(H / 64, w_left / 64, 2 * n), dim3(256), 0, tiles,
                 tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
-    else
+    } else {
       MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips, dim3((H + 31) / 32, (w_left + 31) / 32, 2 * n), dim3(32, 8), 0,
                 tiles, tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
+    }
     if (same_shape) {
-      // left strips come from the aligned staging buffer, top strips from the tiles
-      if ((rc = launch_any(ctx, cfg_left, f64, ws, status, pair0, n, -1, vec_top, k, nullptr))) return rc;
+      // left strips come from the aligned staging buffer, top strips from the tiles (or from staging too)
+      if ((rc = launch_any(ctx, cfg_left, f64, ws, status, pair0, n, -1, vec_strips, k, nullptr))) return rc;
     } else {
       if ((rc = launch_any(ctx, cfg_left, f64, ws, status, pair0, n, 1, true, k, nullptr))) return rc;
-      if ((rc = launch_any(ctx, cfg_top, f64, ws, status, pair0, n, 0, vec_top, k, nullptr))) return rc;
+      if ((rc = launch_any(ctx, cfg_top, f64, ws, status, pair0, n, 0, vec_strips, k, nullptr))) return rc;
     }
     MS_LAUNCH(ctx, "k_peaks_candidates", k_peaks_candidates, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, ws.partial,
                        ws.partial_stride, cfg_top.nblk, cfg_left.nblk, k, 2, ws.peaks, ws.cand, ws.acc);
@@ -2251,6 +2406,25 @@ extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles,
                      out, status, subpixel ? ws.ups : (const UpsState*)nullptr);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
+}
+
+extern "C" int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h,
+                                       int tile_w, int64_t tile_pitch, const int32_t* pair_idx,
+                                       const uint8_t* pair_dir, int n_pairs, int edge_width, unsigned flags,
+                                       double* out, int8_t* status) {
+  return register_pairs_impl(ctx, tiles, n_tiles, tile_h, tile_w, tile_pitch, nullptr, MISTITCH_FF_NONE, pair_idx, pair_dir,
+                             n_pairs, edge_width, flags, out, status);
+}
+
+extern "C" int mistitch_register_pairs_flatfield(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h,
+                                                 int tile_w, int64_t tile_pitch, const void* flatfield, int ff_type,
+                                                 const int32_t* pair_idx, const uint8_t* pair_dir, int n_pairs,
+                                                 int edge_width, unsigned flags, double* out, int8_t* status) {
+  MS_REQUIRE(flatfield, MISTITCH_ERR_ARG, "flatfield is NULL");
+  MS_REQUIRE(ff_type == MISTITCH_FF_F32 || ff_type == MISTITCH_FF_F64, MISTITCH_ERR_ARG, "unknown flatfield type %d",
+             ff_type);
+  return register_pairs_impl(ctx, tiles, n_tiles, tile_h, tile_w, tile_pitch, flatfield, ff_type, pair_idx, pair_dir,
+                             n_pairs, edge_width, flags, out, status);
 }
 
 // Shared body of mistitch_pcm / mistitch_pcm_topk: one pair of free-standing strips.
@@ -2377,7 +2551,7 @@ extern "C" int mistitch_refine_pairs(mistitch_ctx* ctx, const uint16_t* tiles, i
   uint16_t* staging = (uint16_t*)ctx->staging.ptr;
   const bool vec_top = aligned16(tiles) && (W % 8 == 0) && (tile_pitch % 8 == 0);
   MS_LAUNCH(ctx, "k_setup_pairs", k_setup_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, tiles, tile_pitch, H, W, w_left,
-            w_top, pair_idx, pair_dir, n_pairs, n_tiles, staging, chunk, desc, status);
+            w_top, pair_idx, pair_dir, n_pairs, n_tiles, staging, chunk, desc, status, (int64_t)2 * w_left * H, 0);
   for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {
     const int n = std::min(chunk, n_pairs - pair0);
     if (vec_top && H % 64 == 0 && w_left % 64 == 0)

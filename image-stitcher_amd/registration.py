@@ -74,7 +74,7 @@ def to_device_u16(arr, device=None):
 # ----------------------------------------------------------------------------
 def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WIDTH, fft: str = "f64",
                    ctx: Optional[_lib.Context] = None, out=None, status=None, subpixel: bool = False,
-                   upsample_factor: int = 100):
+                   upsample_factor: int = 100, flatfield=None):
     """Register every (first, second) tile pair on the device.
 
     tiles     [N, H, W] uint16 CUDA tensor (or NumPy array, uploaded)
@@ -86,6 +86,9 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
     ``subpixel`` adds the upsampled-DFT estimate (SubpixelConfig(upsample_factor=100,
     use_subpixel=True) at tile_registration.py:574) as the reference does when
     scikit-image is installed; y and x are then fractional.
+    ``flatfield`` ([H, W] float32 or float64): the tiles are raw and the strips are corrected
+    on the way, with the results of correcting whole tiles first
+    (apply_flatfield_to_image, tile_registration.py:2142-2181).
     """
     torch = _torch()
     tiles = to_device_u16(tiles)
@@ -109,6 +112,17 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
     if subpixel:
         ctx.set_upsample_factor(upsample_factor)
         flags |= REG_SUBPIXEL
+    if flatfield is not None:
+        ff = flatfield if isinstance(flatfield, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(flatfield))
+        if tuple(ff.shape) != (h, w):
+            raise ValueError(f"Flatfield shape {tuple(ff.shape)} doesn't match image shape {(h, w)}")
+        if ff.dtype not in (torch.float32, torch.float64):
+            ff = ff.to(torch.float64)
+        ff = ff.to(dev).contiguous()
+        ff_type = _lib.FF_F32 if ff.dtype == torch.float32 else _lib.FF_F64
+        check(lib.mistitch_register_pairs_flatfield(ctx.handle, ptr(tiles), n, h, w, h * w, ptr(ff), ff_type, ptr(pi),
+                                                    ptr(pd_), n_pairs, int(edge_width), flags, ptr(out), ptr(status)))
+        return out, status
     check(lib.mistitch_register_pairs(ctx.handle, ptr(tiles), n, h, w, h * w, ptr(pi), ptr(pd_), n_pairs,
                                       int(edge_width), flags, ptr(out), ptr(status)))
     return out, status

@@ -104,6 +104,18 @@ int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tile
                             const uint8_t* pair_dir, int n_pairs, int edge_width, unsigned flags,
                             double* out, int8_t* status);
 
+/* mistitch_register_pairs on RAW tiles with the flatfield of the registration channel
+ * applied on the way: the edge strips are extracted, corrected (trunc(clip(v / ff)), one
+ * flatfield plane of tile_h x tile_w, ff_type MISTITCH_FF_F32 / _F64) and staged in one
+ * pass, so only the quarter of every tile that lies in strips is ever corrected.  Same
+ * results as correcting whole tiles first, which is what the reference does when it
+ * loads them (load_batch_images -> apply_flatfield_to_image,
+ * tile_registration.py:2184-2279, 2142-2181) before process_neighborhood_batch.        */
+int mistitch_register_pairs_flatfield(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h,
+                                      int tile_w, int64_t tile_pitch, const void* flatfield, int ff_type,
+                                      const int32_t* pair_idx, const uint8_t* pair_dir, int n_pairs,
+                                      int edge_width, unsigned flags, double* out, int8_t* status);
+
 /* Integer hill climb of the strip NCC around given start shifts: from start_yx the
  * best of the 3 x 3 integer neighbours (first of equal maxima, row-major) is taken
  * while it strictly improves, within +-r of the start and the tile extent, at most

@@ -266,3 +266,24 @@ def test_select_best_registration_channel(reg):
     want = int(np.argmax([np.mean([np.var(acq[c, t][:, -64:][::16, ::16].astype(np.float32)) for t in fovs])
                           for c in range(3)]))
     assert reg.select_best_registration_channel(acq, fovs, 64) == want == 1
+
+
+@pytest.mark.parametrize("shape,edge,dt", [((256, 256), 64, np.float32), ((128, 320), 64, np.float64),
+                                           ((200, 300), 50, np.float32)])
+def test_register_pairs_with_fused_flatfield(reg, shape, edge, dt):
+    """Strips corrected on the way == whole tiles corrected first (oracle), featureless test included."""
+    from oracle import fusion as ofu
+    h, w = shape
+    g = synth.make_grid(70 + h, 2, 3, h, w, overlap=0.15, jitter=3)
+    ff = synth.make_flatfield(h, w, dtype=np.dtype(dt), amplitude=0.5)
+    tiles = g.tiles.copy()
+    tiles[0] = np.rint(3000.0 * ff.astype(np.float64)).astype(np.uint16)  # flat once corrected: featureless
+    corrected = np.stack([ofu.apply_flatfield(t, ff) for t in tiles])
+    ref, ref_status = oreg.register_pairs(corrected, g.pair_idx, g.pair_dir, edge, polish=False)
+    out, status = reg.register_pairs(tiles, g.pair_idx, g.pair_dir, edge, flatfield=ff)
+    out, status = out.cpu().numpy(), status.cpu().numpy()
+    assert np.array_equal(status != 0, ref_status != 0)
+    assert (status != 0).any() and (status == 0).any()
+    ok = status == 0
+    assert np.array_equal(out[ok, 1:], ref[ok, 1:])
+    assert np.allclose(out[ok, 0], ref[ok, 0], rtol=0, atol=1e-12)
