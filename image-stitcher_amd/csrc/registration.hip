@@ -744,33 +744,34 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   if (k <= 2) {
     // The production case: one scan keeps each lane's two best values, then k argmax
     // rounds in which a lane whose best was taken offers its second best.
-    Peak b1{-INFINITY, -1, -1}, b2{-INFINITY, -1, -1};
+    // Values are compared unscaled (the scale is a power of two on this path, so nothing
+    // changes order or creates ties) and carried as (value, key) only.
+    T v1 = neg_inf, v2 = neg_inf;
+    int k1 = -1, k2 = -1;
     Peak ba{-INFINITY, -1, -1};  // largest magnitude, first in row-major order (subpixel stage only)
+    auto offer = [&](T v, int key) {
+      const bool gt1 = v > v1 || (v == v1 && key > k1);
+      const bool gt2 = v > v2 || (v == v2 && key > k2);
+      v2 = gt1 ? v1 : (gt2 ? v : v2);
+      k2 = gt1 ? k1 : (gt2 ? key : k2);
+      v1 = gt1 ? v : v1;
+      k1 = gt1 ? key : k1;
+    };
     for (int e = tid; e < NF * L; e += kThreads) {
       const int f = e >> lL, l = e & (L - 1);
-      const int a0 = addr(f, l);
-      const cx<T> v = buf[a0];
+      const cx<T> v = buf[addr(f, l)];
       const int s = s0 + 2 * f;
       const int key0 = d.transposed ? l * S + s : s * L + l;
       const int key1 = d.transposed ? key0 + 1 : key0 + L;
-      const Peak c0{(double)v.x * scale, key0, 2 * a0}, c1{(double)v.y * scale, key1, 2 * a0 + 1};
-      if (peak_better(c0.val, c0.key, b1.val, b1.key)) {
-        b2 = b1;
-        b1 = c0;
-      } else if (peak_better(c0.val, c0.key, b2.val, b2.key)) {
-        b2 = c0;
-      }
-      if (peak_better(c1.val, c1.key, b1.val, b1.key)) {
-        b2 = b1;
-        b1 = c1;
-      } else if (peak_better(c1.val, c1.key, b2.val, b2.key)) {
-        b2 = c1;
-      }
+      offer(v.x, key0);
+      offer(v.y, key1);
       if (partial_abs != nullptr) {
-        if (first_better(fabs(c0.val), c0.key, ba.val, ba.key)) ba = Peak{fabs(c0.val), c0.key, 0};
-        if (first_better(fabs(c1.val), c1.key, ba.val, ba.key)) ba = Peak{fabs(c1.val), c1.key, 0};
+        const double a0v = fabs((double)v.x * scale), a1v = fabs((double)v.y * scale);
+        if (first_better(a0v, key0, ba.val, ba.key)) ba = Peak{a0v, key0, 0};
+        if (first_better(a1v, key1, ba.val, ba.key)) ba = Peak{a1v, key1, 0};
       }
     }
+    Peak b1{k1 >= 0 ? (double)v1 * scale : -INFINITY, k1, k1}, b2{k2 >= 0 ? (double)v2 * scale : -INFINITY, k2, k2};
     if (partial_abs != nullptr) {
       const Peak best = block_argmax_first(ba, red);
       if (tid == 0) partial_abs[(int64_t)blockIdx.y * abs_stride + blockIdx.x] = best;
