@@ -223,11 +223,16 @@ __device__ __forceinline__ void fft_pass(cx<T>* buf, const Addr& addr, int nfft,
   }
 }
 
-template <typename T, bool INV, class Addr>
+// MAXR: largest radix the calling kernel's plans may contain.  A kernel is given the registers
+// of its widest butterfly whether or not a plan uses it, so kernels whose plans stop at
+// radix 8 leave radix 16 out (complex128 radix-16 butterflies cost 154 VGPRs, radix-8 ones 90).
+template <typename T, bool INV, int MAXR, class Addr>
 __device__ __forceinline__ void fft_dispatch(int radix, cx<T>* buf, const Addr& addr, int nfft, int N,
                                              int n, const Twiddles<T>& tw, int tid, int nthr) {
   switch (radix) {
-    case 16: fft_pass<T, 16, INV>(buf, addr, nfft, N, n, tw, tid, nthr); break;
+    case 16:
+      if constexpr (MAXR >= 16) fft_pass<T, 16, INV>(buf, addr, nfft, N, n, tw, tid, nthr);
+      break;
     case 8: fft_pass<T, 8, INV>(buf, addr, nfft, N, n, tw, tid, nthr); break;
     case 4: fft_pass<T, 4, INV>(buf, addr, nfft, N, n, tw, tid, nthr); break;
     default: fft_pass<T, 2, INV>(buf, addr, nfft, N, n, tw, tid, nthr); break;
@@ -237,25 +242,25 @@ __device__ __forceinline__ void fft_dispatch(int radix, cx<T>* buf, const Addr& 
 // Forward transform of nfft sequences held in LDS.  Caller must have
 // synchronised after filling buf and the twiddle tables; returns with the block
 // synchronised.
-template <typename T, class Addr>
+template <typename T, int MAXR = 16, class Addr>
 __device__ __forceinline__ void fft_forward(cx<T>* buf, const Addr& addr, int nfft, const FftPlanDev& plan,
                                             const Twiddles<T>& tw, int tid, int nthr) {
   int n = plan.n;
   for (int i = 0; i < plan.npass; ++i) {
-    fft_dispatch<T, false>(plan.radix[i], buf, addr, nfft, plan.n, n, tw, tid, nthr);
+    fft_dispatch<T, false, MAXR>(plan.radix[i], buf, addr, nfft, plan.n, n, tw, tid, nthr);
     n /= plan.radix[i];
     __syncthreads();
   }
 }
 
 // Unnormalised inverse transform (digit-reversed in, natural out).
-template <typename T, class Addr>
+template <typename T, int MAXR = 16, class Addr>
 __device__ __forceinline__ void fft_inverse(cx<T>* buf, const Addr& addr, int nfft, const FftPlanDev& plan,
                                             const Twiddles<T>& tw, int tid, int nthr) {
   int n = 1;
   for (int i = plan.npass - 1; i >= 0; --i) {
     n *= plan.radix[i];
-    fft_dispatch<T, true>(plan.radix[i], buf, addr, nfft, plan.n, n, tw, tid, nthr);
+    fft_dispatch<T, true, MAXR>(plan.radix[i], buf, addr, nfft, plan.n, n, tw, tid, nthr);
     __syncthreads();
   }
 }

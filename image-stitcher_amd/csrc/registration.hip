@@ -94,6 +94,11 @@ __host__ __device__ __forceinline__ int spectrum_pitch(int L) {
 // (pos / 8) * slab_pitch + s * 8 + pos % 8.  The column pass then reads whole
 // slabs contiguously; the scattered accesses are all on the WRITING side, where
 // the memory system can batch them.
+// Largest radix of the long-axis plans: complex128 lines run radix-8 passes (one more pass,
+// but 90 instead of 154 VGPRs: five waves per SIMD instead of three), complex64 ones radix 16.
+template <typename T>
+constexpr int kLongMaxRadix = sizeof(T) == 8 ? 8 : 16;
+
 constexpr int kSlab = 8;
 __host__ __device__ __forceinline__ int64_t slab_pitch(int S) { return (int64_t)S * kSlab + kSlab; }
 __host__ __device__ __forceinline__ int64_t slab_pair_elems(int S, int L) { return slab_pitch(S) * (L / kSlab); }
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
   }
   __syncthreads();
   MS_STAMP(0, 1);
-  fft_forward<T>(buf, addr, NF, planL, tw, tid, kThreads);
+  fft_forward<T, kLongMaxRadix<T>>(buf, addr, NF, planL, tw, tid, kThreads);
   MS_STAMP(0, 2);
   // element (s0 + f, pos) -> slab pos / 8; the NF lines of this block are adjacent in every slab
   cx<T>* out = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L) + (int64_t)s0 * kSlab;
@@ -720,7 +725,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   }
   __syncthreads();
   MS_STAMP(2, 1);
-  fft_inverse<T>(buf, addr, NF, planL, tw, tid, kThreads);
+  fft_inverse<T, kLongMaxRadix<T>>(buf, addr, NF, planL, tw, tid, kThreads);
   MS_STAMP(2, 2);
   const double scale = 1.0 / ((double)S * (double)L);
   if (pcm_out != nullptr) {
@@ -1716,8 +1721,8 @@ __global__ void k_peaks_to_arrays(const Peak* peaks, int k, int img_w, int32_t* 
 // ---------------------------------------------------------------------------
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-static int build_plan(mistitch_ctx* ctx, int n, bool f64, FftPlanDev* out) {
-  const long long key = (long long)n * 2 + (f64 ? 1 : 0);
+static int build_plan(mistitch_ctx* ctx, int n, bool f64, FftPlanDev* out, int max_radix = 16) {
+  const long long key = ((long long)n * 2 + (f64 ? 1 : 0)) * 32 + max_radix;
   auto it = ctx->plans.find(key);
   if (it != ctx->plans.end()) {
     *out = it->second.dev;
@@ -1730,8 +1735,9 @@ static int build_plan(mistitch_ctx* ctx, int n, bool f64, FftPlanDev* out) {
   int lg = 0;
   while ((1 << lg) < n) ++lg;
   int np = 0;
-  if (lg % 4) ph.dev.radix[np++] = 1 << (lg % 4);
-  for (int i = 0; i < lg / 4; ++i) ph.dev.radix[np++] = 16;
+  const int lr = max_radix >= 16 ? 4 : 3;
+  if (lg % lr) ph.dev.radix[np++] = 1 << (lg % lr);
+  for (int i = 0; i < lg / lr; ++i) ph.dev.radix[np++] = 1 << lr;
   ph.dev.npass = np;
   {
     long long prod = 1;
@@ -1891,7 +1897,7 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   cfg->L = L;
   int rc = build_plan(ctx, S, f64, &cfg->planS);
   if (rc) return rc;
-  rc = build_plan(ctx, L, f64, &cfg->planL);
+  rc = build_plan(ctx, L, f64, &cfg->planL, f64 ? kLongMaxRadix<double> : kLongMaxRadix<float>);
   if (rc) return rc;
   const size_t esz = f64 ? 16 : 8;
   std::vector<uint16_t> mpos(L);
