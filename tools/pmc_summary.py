@@ -29,8 +29,10 @@ def short_name(full):
     if name == "k_fuse":
         mode = m.group(3).split(",")[0].strip()
         return "k_fuse_feather" if mode == "1" else "k_fuse_overwrite"
-    if name == "k_transpose_strips64":
-        return "k_transpose_strips"
+    aliases = {"k_transpose_strips64": "k_transpose_strips", "k_stage_strips64": "k_stage_strips",
+               "k_stage_strips_any": "k_stage_strips", "k_edge_stats_staged": "k_edge_stats"}
+    if name in aliases:
+        return aliases[name]
     return name
 
 
