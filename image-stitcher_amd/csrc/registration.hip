@@ -573,7 +573,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
                                                             FftPlanDev planS, FftPlanDev planL,
                                                             const CpsUnit* __restrict__ units, int rs,
                                                             const cx<T>* slabs, cx<T>* spectrum, T eps,
-                                                            cx<T>* keep_r) {
+                                                            cx<T>* keep_r, const uint16_t* __restrict__ pos2stored,
+                                                            int n_stored) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
   const int p = pair0 + blockIdx.y;
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   const CpsUnit un = units[blockIdx.x];
   const int na = un.na, ncol = un.na + un.nb;
   const int tid = threadIdx.x;
-  const int Lp = spectrum_pitch<T>(L);
+  const int Lp = spectrum_pitch<T>(n_stored);
   cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
   const cx<T>* Zs = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
   const int64_t sp = slab_pitch(S);
@@ -660,9 +661,12 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   }
   fft_inverse<T>(buf, addr, na, planS, tw, tid, kThreads);
   MS_STAMP(1, 4);
+  // the intermediate spectrum holds the stored columns only, packed in ascending position
+  // order: the last pass then reads whole rows contiguously
+  const int col0 = pos2stored[un.a0];
   for (int e = tid; e < S * na; e += kThreads) {
     const int s = e >> lna, c = e & (na - 1);
-    Z[(int64_t)s * Lp + un.a0 + c] = buf[s * rs + c];
+    Z[(int64_t)s * Lp + col0 + c] = buf[s * rs + c];
   }
   MS_STAMP(1, 5);
 }
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   const Twiddles<T> tw = load_twiddles<T>(buf + NF * addr.fstride, planL, tid, kThreads);
   const int s0 = blockIdx.x * NF * 2;
   const int lL = 31 - __builtin_clz(L);  // a power of two on this path
-  const int Lp = spectrum_pitch<T>(L);
+  const int Lp = spectrum_pitch<T>(n_stored);
   const cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
   MS_STAMP(2, 0);
   {
@@ -702,9 +706,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       for (int u = 0; u < U; ++u) {
         const int e = min(e0 + u * kThreads, NF * n_stored - 1);  // clamp, do not branch around the loads
         const int f = NF == 1 ? 0 : e / n_stored, i = e - f * n_stored;
-        const int pos = stored_pos[i];
-        g1[u] = Z[(int64_t)(s0 + 2 * f) * Lp + pos];
-        g2[u] = Z[(int64_t)(s0 + 2 * f + 1) * Lp + pos];
+        g1[u] = Z[(int64_t)(s0 + 2 * f) * Lp + i];
+        g2[u] = Z[(int64_t)(s0 + 2 * f + 1) * Lp + i];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -2220,7 +2223,7 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
   const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
   MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<T>), dim3(cfg.n_units, n), dim3(kThreads), cfg.lds_cps, ws.desc, status,
             pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps,
-            ws.n_up ? slabs : (cx<T>*)nullptr);
+            ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
   if ((rc = allow_lds(ctx, k_fft_long_inv<T>, cfg.lds_inv))) return rc;
   MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv<T>), dim3(cfg.S / (2 * cfg.NF_inv), n), dim3(kThreads), cfg.lds_inv, ws.desc,
                      status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored,
