@@ -121,6 +121,11 @@ struct Dft {
   }
 };
 
+// Workgroup barrier that orders LDS traffic only.  The transforms communicate through LDS alone,
+// and unlike __syncthreads() this does not wait for global loads a caller has in flight (the
+// next block of input being fetched into registers during the arithmetic).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // LDS addressing of element i of transform f.
 //  Line: transforms are contiguous padded lines (pad one element per 256 B so
 //        that the stride-R accesses of the late passes spread over all banks).
@@ -249,7 +254,7 @@ __device__ __forceinline__ void fft_forward(cx<T>* buf, const Addr& addr, int nf
   for (int i = 0; i < plan.npass; ++i) {
     fft_dispatch<T, false, MAXR>(plan.radix[i], buf, addr, nfft, plan.n, n, tw, tid, nthr);
     n /= plan.radix[i];
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -261,7 +266,7 @@ __device__ __forceinline__ void fft_inverse(cx<T>* buf, const Addr& addr, int nf
   for (int i = plan.npass - 1; i >= 0; --i) {
     n *= plan.radix[i];
     fft_dispatch<T, true, MAXR>(plan.radix[i], buf, addr, nfft, plan.n, n, tw, tid, nthr);
-    __syncthreads();
+    lds_barrier();
   }
 }
 

@@ -99,6 +99,14 @@ __host__ __device__ __forceinline__ int spectrum_pitch(int L) {
 template <typename T>
 constexpr int kLongMaxRadix = sizeof(T) == 8 ? 8 : 16;
 
+// Column pass: complex128 blocks run 512 lanes with radix-8 plans (under 128 VGPRs, four waves
+// per SIMD), complex64 ones 256 lanes with radix 16 (their LDS footprint already allows four
+// workgroups per CU).
+template <typename T>
+constexpr int kShortMaxRadix = sizeof(T) == 8 ? 8 : 16;
+template <typename T>
+constexpr int kShortThreads = 512;
+
 constexpr int kSlab = 8;
 __host__ __device__ __forceinline__ int64_t slab_pitch(int S) { return (int64_t)S * kSlab + kSlab; }
 __host__ __device__ __forceinline__ int64_t slab_pair_elems(int S, int L) { return slab_pitch(S) * (L / kSlab); }
@@ -566,15 +574,16 @@ struct CpsUnit {
 };
 
 // Short-axis FFT, cross-power spectrum, short-axis inverse FFT.
-// grid (n_units, pairs_in_pass).
-template <typename T>
-__global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc, const int8_t* status,
-                                                            int pair0, int S, int L, int want_transposed,
-                                                            FftPlanDev planS, FftPlanDev planL,
-                                                            const CpsUnit* __restrict__ units, int rs,
-                                                            const cx<T>* slabs, cx<T>* spectrum, T eps,
-                                                            cx<T>* keep_r, const uint16_t* __restrict__ pos2stored,
-                                                            int n_stored) {
+// grid (n_units, pairs_in_pass), NT lanes.  The unit's [S][2C] block fills the LDS budget of
+// half a CU whatever NT is, so a complex128 pass runs 512 lanes a workgroup: four waves per
+// SIMD instead of two hide the LDS round trip of each radix pass (2.6 instead of 3.1 ms on
+// the 2048 x 256 strips).
+template <typename T, int NT, int MAXR>
+__global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, const int8_t* status, int pair0, int S, int L,
+                                                      int want_transposed, FftPlanDev planS, FftPlanDev planL,
+                                                      const CpsUnit* __restrict__ units, int rs, const cx<T>* slabs,
+                                                      cx<T>* spectrum, T eps, cx<T>* keep_r,
+                                                      const uint16_t* __restrict__ pos2stored, int n_stored) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
   const int p = pair0 + blockIdx.y;
@@ -588,48 +597,58 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
   const int tid = threadIdx.x;
   const int Lp = spectrum_pitch<T>(n_stored);
   cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
-  const cx<T>* Zs = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
   const int64_t sp = slab_pitch(S);
+  const cx<T>* Zs = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
   MS_STAMP(1, 0);
-  const Twiddles<T> tw = load_twiddles<T>(buf + S * rs, planS, tid, kThreads);
+  const Twiddles<T> tw = load_twiddles<T>(buf + S * rs, planS, tid, NT);
+  // the short-axis index tables go to LDS once instead of being looked up in memory per cell
+  uint16_t* mposS = reinterpret_cast<uint16_t*>(buf + S * rs + Twiddles<T>::entries(S));
+  uint16_t* rowS = mposS + S;  // position -> row of the kept spectrum (ascending signed frequency)
+  for (int q = tid; q < S; q += NT) {
+    mposS[q] = planS.mpos[q];
+    rowS[q] = (uint16_t)((planS.pos2freq[q] + S / 2) & (S - 1));
+  }
   const int lncol = 31 - __builtin_clz(ncol), lna = 31 - __builtin_clz(na);  // 8 or 16 columns: shifts, not divisions
+  const int n_elem = S * ncol;
+  // looked up here, with the column loads behind them, not where they are used: column c of a
+  // lane's cells is the same on every trip (na is a power of two no larger than NT)
+  const int mp = planL.mpos[un.a0 + (tid & (na - 1))];
+  const int col0 = pos2stored[un.a0];
   {
-    constexpr int U = 16;  // loads in flight per lane before the first LDS write
-    for (int e0 = tid; e0 < S * ncol; e0 += kThreads * U) {
+    // Lane tid's k-th element is e = tid + k NT: the same column, NT / ncol rows further down, so
+    // one per-lane offset and a uniform step address every load and every LDS write.
+    constexpr int U = 4096 / NT;  // loads in flight per lane before the first LDS write
+    const int e_t = min(tid, n_elem - 1);
+    const int c_t = e_t & (ncol - 1);
+    const int pos_t = c_t < na ? un.a0 + c_t : un.b0 + (c_t - na);
+    const cx<T>* src = Zs + (pos_t / kSlab) * sp + (e_t >> lncol) * kSlab + pos_t % kSlab;
+    const int src_step = (NT >> lncol) * kSlab;
+    cx<T>* dst = buf + (tid >> lncol) * rs + (tid & (ncol - 1));
+    const int dst_step = (NT >> lncol) * rs;
+    for (int e0 = tid, k0 = 0; e0 < n_elem; e0 += NT * U, k0 += U) {
       cx<T> r[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = min(e0 + u * kThreads, S * ncol - 1);  // clamp, do not branch around the load
-        const int s = e >> lncol, c = e & (ncol - 1);
-        const int pos = c < na ? un.a0 + c : un.b0 + (c - na);
-        r[u] = Zs[(pos / kSlab) * sp + s * kSlab + pos % kSlab];
-      }
+      for (int u = 0; u < U; ++u) r[u] = src[e0 + u * NT < n_elem ? (k0 + u) * src_step : 0];  // never branch around a load
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         MS_PIN(r[u].x);
         MS_PIN(r[u].y);
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int e = e0 + u * kThreads;
-        if (e < S * ncol) {
-          const int s = e >> lncol, c = e & (ncol - 1);
-          buf[s * rs + c] = r[u];
-        }
-      }
+      for (int u = 0; u < U; ++u)
+        if (e0 + u * NT < n_elem) dst[(k0 + u) * dst_step] = r[u];
     }
   }
-  __syncthreads();
+  lds_barrier();
   ColAddr<T> addr{rs};
   MS_STAMP(1, 1);
-  fft_forward<T>(buf, addr, ncol, planS, tw, tid, kThreads);
+  fft_forward<T, MAXR>(buf, addr, ncol, planS, tw, tid, NT);
   MS_STAMP(1, 2);
-  for (int e = tid; e < S * na; e += kThreads) {
+  const bool partner_in_a = mp >= un.a0 && mp < un.a0 + na;
+  const int pc = partner_in_a ? (mp - un.a0) : (na + mp - un.b0);
+  for (int e = tid; e < S * na; e += NT) {
     const int q = e >> lna, c = e & (na - 1);
-    const int mp = planL.mpos[un.a0 + c];
-    const bool partner_in_a = mp >= un.a0 && mp < un.a0 + na;
-    const int pc = partner_in_a ? (mp - un.a0) : (na + mp - un.b0);
-    const int q2 = planS.mpos[q];
+    const int q2 = mposS[q];
     if (partner_in_a && (q2 * rs + pc) < (q * rs + c)) continue;  // the partner cell's owner writes both
     const cx<T> z = buf[q * rs + c];
     const cx<T> zm = buf[q2 * rs + pc];
@@ -645,26 +664,25 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps(const PairDesc* desc
     buf[q * rs + c] = mk<T>(fx, fy);
     if (partner_in_a && (q2 * rs + pc) != (q * rs + c)) buf[q2 * rs + pc] = mk<T>(fx, -fy);
   }
-  __syncthreads();
+  lds_barrier();
   MS_STAMP(1, 3);
   if (keep_r != nullptr) {
     // the subpixel stage wants the normalised spectrum itself: it replaces this unit's own
     // columns of the slab buffer, which no other workgroup reads, with the rows reordered
     // to ascending signed frequency -S/2 .. S/2-1
     cx<T>* Rs = keep_r + (int64_t)blockIdx.y * slab_pair_elems(S, L);
-    for (int e = tid; e < S * na; e += kThreads) {
+    for (int e = tid; e < S * na; e += NT) {
       const int q = e >> lna, c = e & (na - 1);
       const int pos = un.a0 + c;
-      const int kk = (planS.pos2freq[q] + S / 2) & (S - 1);
-      Rs[(pos / kSlab) * sp + kk * kSlab + pos % kSlab] = buf[q * rs + c];
+      Rs[(pos / kSlab) * sp + rowS[q] * kSlab + pos % kSlab] = buf[q * rs + c];
     }
+    lds_barrier();  // the inverse transform's first pass overwrites cells other lanes copy out here
   }
-  fft_inverse<T>(buf, addr, na, planS, tw, tid, kThreads);
+  fft_inverse<T, MAXR>(buf, addr, na, planS, tw, tid, NT);
   MS_STAMP(1, 4);
   // the intermediate spectrum holds the stored columns only, packed in ascending position
   // order: the last pass then reads whole rows contiguously
-  const int col0 = pos2stored[un.a0];
-  for (int e = tid; e < S * na; e += kThreads) {
+  for (int e = tid; e < S * na; e += NT) {
     const int s = e >> lna, c = e & (na - 1);
     Z[(int64_t)s * Lp + col0 + c] = buf[s * rs + c];
   }
@@ -1738,7 +1756,7 @@ static int build_plan(mistitch_ctx* ctx, int n, bool f64, FftPlanDev* out, int m
   int lg = 0;
   while ((1 << lg) < n) ++lg;
   int np = 0;
-  const int lr = max_radix >= 16 ? 4 : 3;
+  const int lr = max_radix >= 16 ? 4 : (max_radix >= 8 ? 3 : 2);
   if (lg % lr) ph.dev.radix[np++] = 1 << (lg % lr);
   for (int i = 0; i < lg / lr; ++i) ph.dev.radix[np++] = 1 << lr;
   ph.dev.npass = np;
@@ -1898,7 +1916,7 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   }
   cfg->S = S;
   cfg->L = L;
-  int rc = build_plan(ctx, S, f64, &cfg->planS);
+  int rc = build_plan(ctx, S, f64, &cfg->planS, f64 ? kShortMaxRadix<double> : kShortMaxRadix<float>);
   if (rc) return rc;
   rc = build_plan(ctx, L, f64, &cfg->planL, f64 ? kLongMaxRadix<double> : kLongMaxRadix<float>);
   if (rc) return rc;
@@ -1916,7 +1934,8 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   }
   MS_REQUIRE(C >= 1, MISTITCH_ERR_UNSUPPORTED, "no column-pass decomposition for long side %d", L);
   cfg->C = C;
-  cfg->lds_cps = ((size_t)S * 2 * C + (f64 ? Twiddles<double>::entries(S) : Twiddles<float>::entries(S))) * esz;
+  cfg->lds_cps = ((size_t)S * 2 * C + (f64 ? Twiddles<double>::entries(S) : Twiddles<float>::entries(S))) * esz +
+                 ((size_t)S * 4 + 15) / 16 * 16;  // + two uint16 index tables of the short axis
   MS_REQUIRE(cfg->lds_cps <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "short side %d needs %zu B of LDS", S, cfg->lds_cps);
   {
     std::vector<uint16_t> pos2freq(L), pos2stored(L, 0xffff);
@@ -2219,9 +2238,10 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
     MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd<T, false>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd,
                        ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, slabs);
   }
-  if ((rc = allow_lds(ctx, k_fft_short_cps<T>, cfg.lds_cps))) return rc;
+  constexpr int kNT = kShortThreads<T>, kSR = kShortMaxRadix<T>;
+  if ((rc = allow_lds(ctx, k_fft_short_cps<T, kNT, kSR>, cfg.lds_cps))) return rc;
   const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
-  MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<T>), dim3(cfg.n_units, n), dim3(kThreads), cfg.lds_cps, ws.desc, status,
+  MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<T, kNT, kSR>), dim3(cfg.n_units, n), dim3(kNT), cfg.lds_cps, ws.desc, status,
             pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps,
             ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
   if ((rc = allow_lds(ctx, k_fft_long_inv<T>, cfg.lds_inv))) return rc;
