@@ -45,7 +45,7 @@ __device__ unsigned long long g_stamps[3][4096][8];
 constexpr int kThreads = 256;
 constexpr int kMaxK = 16;       // peaks a block / a pair can report
 constexpr int kNumCand = 32;    // 2 peaks x 16 signed interpretations
-constexpr int kNccChunks = 32;  // workgroups cooperating on one candidate
+constexpr int kNccChunks = 8;   // workgroups cooperating on one candidate
 constexpr int kCandSlots = kNumCand + 1;  // the last slot holds the subpixel estimate's rounded shift (flag 1 when unused)
 constexpr int kUpsMax = 160;    // largest upsampled region side (ceil(1.5 * upsample factor))
 constexpr int kUpsRows = 15;    // upsampled rows per block of the second stage
@@ -1449,7 +1449,8 @@ __device__ __forceinline__ void moments_of_rows(const uint16_t* a, int64_t pa, c
   MomentAcc acc;
   unsigned long long tail[5] = {0, 0, 0, 0, 0};
   const int ngroups = ncols >> 3;
-  for (int r = r_begin; r < r_end; r += r_step) {
+  int r = r_begin;
+  for (; r < r_end; r += r_step) {
     const uint16_t* ra = a + (int64_t)r * pa;
     const uint16_t* rb = b + (int64_t)r * pb;
     for (int g = threadIdx.x; g < ngroups; g += kThreads)
@@ -1469,15 +1470,39 @@ __device__ __forceinline__ void moments_of_rows(const uint16_t* a, int64_t pa, c
   for (int i = 0; i < 5; ++i) v[i] += tail[i];
 }
 
+// Sum of a 64-bit value over the 64 lanes of a wave, the same in every lane.  Data-parallel
+// primitives and lane reads only: the cross-lane shuffles of __shfl_xor go through the LDS
+// pipeline, and with five sums per wave and thousands of short workgroups that pipeline, not
+// memory, set the pace of the NCC kernel.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xf, 0xf, true);
+  const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), CTRL, 0xf, 0xf, true);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+  v += dpp_u64<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
+  v += dpp_u64<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
+  v += dpp_u64<0x141>(v);  // row_half_mirror: the other quad of each 8 lanes
+  v += dpp_u64<0x140>(v);  // row_mirror: the other half of each 16 lanes
+  unsigned long long total = 0;
+#pragma unroll
+  for (int row = 0; row < 4; ++row) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, 16 * row);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), 16 * row);
+    total += ((unsigned long long)hi << 32) | lo;
+  }
+  return total;
+}
+
 // Sum v[0..5) over the workgroup and add it to acc[0..5) with integer atomics
 // (exact and order independent).
 __device__ __forceinline__ void reduce_moments(unsigned long long (&v)[5], unsigned long long* red,
                                                unsigned long long* acc) {
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
-  }
+  for (int i = 0; i < 5; ++i) v[i] = wave_sum_u64(v[i]);
+  // one set of atomics per workgroup: four times as many (one per wave) contend enough on the
+  // candidate's five words to cost more than this barrier
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
 #pragma unroll
@@ -1492,25 +1517,35 @@ __device__ __forceinline__ void reduce_moments(unsigned long long (&v)[5], unsig
 }
 
 // Exact moments (sum a, sum b, sum a^2, sum b^2, sum ab) over the overlap of a
-// candidate shift.  grid (kNccChunks, kCandSlots, pairs_in_pass).
+// candidate shift.  One-dimensional grid of 8 * ceil(pairs_in_pass / 8) * kCandSlots * kNccChunks
+// workgroups.  Workgroups go to the eight XCDs in turn, each with an L2 of its own, so
+// workgroup b works for pair (b mod 8) + 8 * (...): every candidate of a pair is then summed
+// on one XCD, whose L2 keeps that pair's two strips while its ~30 overlaps are read from them.
+constexpr int kXcds = 8;
 __global__ __launch_bounds__(kThreads) void k_ncc_accumulate(const PairDesc* desc, const int8_t* status,
-                                                             int pair0, const Cand* cand,
+                                                             int pair0, int n_in_pass, const Cand* cand,
                                                              unsigned long long* acc) {
   __shared__ unsigned long long red[5 * kThreads / 64];
-  const int p = pair0 + blockIdx.z;
+  const int xcd = blockIdx.x % kXcds, seq = blockIdx.x / kXcds;
+  constexpr int kPerPair = kNccChunks * kCandSlots;
+  const int pz = xcd + kXcds * (seq / kPerPair);
+  if (pz >= n_in_pass) return;
+  const int within = seq % kPerPair;
+  const int ci = within / kNccChunks, chunk = within % kNccChunks;
+  const int p = pair0 + pz;
   if (status[p] != MISTITCH_PAIR_OK) return;
-  const Cand c = cand[(int64_t)p * kCandSlots + blockIdx.y];
+  const Cand c = cand[(int64_t)p * kCandSlots + ci];
   if (c.flag != 0) return;
   const PairDesc d = desc[p];
   const int ds = d.transposed ? c.x : c.y;
   const int dl = d.transposed ? c.y : c.x;
   const int s_lo = ds > 0 ? ds : 0, s_hi = d.S + (ds < 0 ? ds : 0);
   const int l_lo = dl > 0 ? dl : 0, l_hi = d.L + (dl < 0 ? dl : 0);
-  if (s_lo + (int)blockIdx.x >= s_hi) return;
+  if (s_lo + chunk >= s_hi) return;
   unsigned long long v[5];
-  moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, s_lo + blockIdx.x, s_hi,
-                  gridDim.x, l_hi - l_lo, v);
-  reduce_moments(v, red, acc + ((int64_t)p * kCandSlots + blockIdx.y) * 5);
+  moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, s_lo + chunk, s_hi,
+                  kNccChunks, l_hi - l_lo, v);
+  reduce_moments(v, red, acc + ((int64_t)p * kCandSlots + ci) * 5);
 }
 
 // ---- exact 128-bit helpers -------------------------------------------------
@@ -1627,10 +1662,7 @@ __device__ double block_ncc(const PairDesc& d, int ty, int tx, unsigned long lon
   moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, s_lo, s_hi, 1,
                   l_hi - l_lo, v);
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v[i] += __shfl_xor(v[i], off);
-  }
+  for (int i = 0; i < 5; ++i) v[i] = wave_sum_u64(v[i]);
   const int wave = threadIdx.x >> 6;
   __syncthreads();  // red may still be read from the previous call
   if ((threadIdx.x & 63) == 0) {
@@ -2429,8 +2461,8 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
     if (subpixel)
       MS_LAUNCH(ctx, "k_ups_finish", k_ups_finish, dim3((n + 63) / 64), dim3(64), 0, ws.desc, status, pair0, n, ws.partial_ups,
                 ws.n_row_blocks, ws.n_up, ws.uf, ws.ups, ws.cand);
-    MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(kNccChunks, kCandSlots, n), dim3(kThreads), 0, ws.desc, status, pair0,
-                       ws.cand, ws.acc);
+    MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(kXcds * ((n + kXcds - 1) / kXcds) * kCandSlots * kNccChunks),
+              dim3(kThreads), 0, ws.desc, status, pair0, n, ws.cand, ws.acc);
   }
   MS_LAUNCH(ctx, "k_finalize", k_finalize, dim3((n_pairs + 63) / 64), dim3(64), 0, ws.desc, status, n_pairs, ws.cand, ws.acc,
                      out, status, subpixel ? ws.ups : (const UpsState*)nullptr);
