@@ -115,19 +115,85 @@ __device__ __forceinline__ bool peak_better(double v, int k, double bv, int bk) 
   return (v > bv) || (v == bv && k > bk);
 }
 
+// ---- wave-wide reductions ---------------------------------------------------
+// Data-parallel primitives (DPP) and lane reads only.  The cross-lane shuffles of __shfl_xor go
+// through the LDS pipeline; with several values per wave and thousands of short workgroups that
+// pipeline, not memory, set the pace of the NCC kernel (2.3 ms with shuffles, 1.5 ms without).
+// Four DPP steps leave every lane of a 16-lane row with the row's result; the four rows are
+// combined through lane reads.
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;  // the other quad of each 8 lanes
+constexpr int kDppMirror = 0x140;      // the other half of each 16 lanes
+
+// Sum of a 64-bit value over the 64 lanes of a wave, the same in every lane.
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
+  const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xf, 0xf, true);
+  const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), CTRL, 0xf, 0xf, true);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+  v += dpp_u64<kDppXor1>(v);
+  v += dpp_u64<kDppXor2>(v);
+  v += dpp_u64<kDppHalfMirror>(v);
+  v += dpp_u64<kDppMirror>(v);
+  unsigned long long total = 0;
+#pragma unroll
+  for (int row = 0; row < 4; ++row) {
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, 16 * row);
+    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), 16 * row);
+    total += ((unsigned long long)hi << 32) | lo;
+  }
+  return total;
+}
+
+
+template <int CTRL>
+__device__ __forceinline__ Peak dpp_peak(const Peak& p) {
+  Peak o;
+  o.val = __longlong_as_double((long long)dpp_u64<CTRL>((unsigned long long)__double_as_longlong(p.val)));
+  o.key = (int)__builtin_amdgcn_update_dpp(0u, (unsigned)p.key, CTRL, 0xf, 0xf, true);
+  o.loc = (int)__builtin_amdgcn_update_dpp(0u, (unsigned)p.loc, CTRL, 0xf, 0xf, true);
+  return o;
+}
+__device__ __forceinline__ Peak lane_peak(const Peak& p, int lane) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(p.val);
+  const unsigned lo = __builtin_amdgcn_readlane((unsigned)bits, lane), hi = __builtin_amdgcn_readlane((unsigned)(bits >> 32), lane);
+  Peak o;
+  o.val = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+  o.key = (int)__builtin_amdgcn_readlane((unsigned)p.key, lane);
+  o.loc = (int)__builtin_amdgcn_readlane((unsigned)p.loc, lane);
+  return o;
+}
+// Wave-wide best peak under a total order `better(v, k, bv, bk)`, the same in every lane.
+template <class Better>
+__device__ __forceinline__ Peak wave_best_peak(Peak mine, Better better) {
+  auto take = [&](const Peak& o) {
+    if (better(o.val, o.key, mine.val, mine.key)) mine = o;
+  };
+  take(dpp_peak<kDppXor1>(mine));
+  take(dpp_peak<kDppXor2>(mine));
+  take(dpp_peak<kDppHalfMirror>(mine));
+  take(dpp_peak<kDppMirror>(mine));
+  Peak best = lane_peak(mine, 0);
+#pragma unroll
+  for (int row = 1; row < 4; ++row) {
+    const Peak o = lane_peak(mine, 16 * row);
+    if (better(o.val, o.key, best.val, best.key)) best = o;
+  }
+  return best;
+}
+
+// Among equal values the SMALLEST key wins (the first occurrence in row-major order, as
+// numpy.argmax reports).
+__device__ __forceinline__ bool first_better(double v, int k, double bv, int bk) {
+  return (v > bv) || (v == bv && k >= 0 && (bk < 0 || k < bk));
+}
+
 // Block-wide argmax of (val, key) carrying loc; result valid in every thread.
 __device__ __forceinline__ Peak block_argmax(Peak mine, Peak* red /*[kThreads/64]*/) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    double ov = __shfl_xor(mine.val, off);
-    int ok = __shfl_xor(mine.key, off);
-    int ol = __shfl_xor(mine.loc, off);
-    if (peak_better(ov, ok, mine.val, mine.key)) {
-      mine.val = ov;
-      mine.key = ok;
-      mine.loc = ol;
-    }
-  }
+  mine = wave_best_peak(mine, peak_better);
   const int wave = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[wave] = mine;
@@ -141,23 +207,9 @@ __device__ __forceinline__ Peak block_argmax(Peak mine, Peak* red /*[kThreads/64
   return best;
 }
 
-// Block-wide argmax where the SMALLEST key wins among equal values (the first
-// occurrence in row-major order, as numpy.argmax reports); result valid in every thread.
-__device__ __forceinline__ bool first_better(double v, int k, double bv, int bk) {
-  return (v > bv) || (v == bv && k >= 0 && (bk < 0 || k < bk));
-}
+// Block-wide argmax where the smallest key wins among equal values; result valid in every thread.
 __device__ __forceinline__ Peak block_argmax_first(Peak mine, Peak* red /*[kThreads/64]*/) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    double ov = __shfl_xor(mine.val, off);
-    int ok = __shfl_xor(mine.key, off);
-    int ol = __shfl_xor(mine.loc, off);
-    if (first_better(ov, ok, mine.val, mine.key)) {
-      mine.val = ov;
-      mine.key = ok;
-      mine.loc = ol;
-    }
-  }
+  mine = wave_best_peak(mine, first_better);
   const int wave = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[wave] = mine;
@@ -232,11 +284,8 @@ __device__ __forceinline__ double sampled_variance(const uint16_t* base, int64_t
     s += v;
     q += v * v;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    s += __shfl_xor(s, off);
-    q += __shfl_xor(q, off);
-  }
+  s = wave_sum_u64(s);
+  q = wave_sum_u64(q);
   const int wave = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) {
@@ -1468,31 +1517,6 @@ __device__ __forceinline__ void moments_of_rows(const uint16_t* a, int64_t pa, c
   acc.totals(v);
 #pragma unroll
   for (int i = 0; i < 5; ++i) v[i] += tail[i];
-}
-
-// Sum of a 64-bit value over the 64 lanes of a wave, the same in every lane.  Data-parallel
-// primitives and lane reads only: the cross-lane shuffles of __shfl_xor go through the LDS
-// pipeline, and with five sums per wave and thousands of short workgroups that pipeline, not
-// memory, set the pace of the NCC kernel.
-template <int CTRL>
-__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long v) {
-  const unsigned lo = __builtin_amdgcn_update_dpp(0u, (unsigned)v, CTRL, 0xf, 0xf, true);
-  const unsigned hi = __builtin_amdgcn_update_dpp(0u, (unsigned)(v >> 32), CTRL, 0xf, 0xf, true);
-  return ((unsigned long long)hi << 32) | lo;
-}
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
-  v += dpp_u64<0xB1>(v);   // quad_perm [1,0,3,2]: lane ^ 1
-  v += dpp_u64<0x4E>(v);   // quad_perm [2,3,0,1]: lane ^ 2
-  v += dpp_u64<0x141>(v);  // row_half_mirror: the other quad of each 8 lanes
-  v += dpp_u64<0x140>(v);  // row_mirror: the other half of each 16 lanes
-  unsigned long long total = 0;
-#pragma unroll
-  for (int row = 0; row < 4; ++row) {
-    const unsigned lo = __builtin_amdgcn_readlane((unsigned)v, 16 * row);
-    const unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), 16 * row);
-    total += ((unsigned long long)hi << 32) | lo;
-  }
-  return total;
 }
 
 // Sum v[0..5) over the workgroup and add it to acc[0..5) with integer atomics
