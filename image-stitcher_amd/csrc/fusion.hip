@@ -373,24 +373,25 @@ __device__ __forceinline__ Px8 corrected8_packed(const Px8& v, const F8& f32, co
   }
 }
 
-// Feather blend of one group that `cnt` (2 or 3) tiles cover completely, all with a
-// usable flatfield plane: loads of all sources issued together, float32 operations
-// rounded one by one in placement order (two pixels per instruction).  `idx` holds
-// the candidate indices, 5 bits each, the LAST placed in the lowest bits.
+// Feather blend of one group that `cnt` (2 to 4) tiles touch, all with a usable flatfield plane
+// and at least one of them covering all 8 pixels: loads of all sources issued together,
+// float32 operations rounded one by one in placement order (two pixels per instruction).
+// A tile that covers the group only partly contributes weight 0 outside its columns (adding
+// 0 * value and 0 changes neither sum); its 16-byte load then runs into the neighbouring row
+// of the same tile, which is why such a tile must not touch the group in its first or last
+// row.  `ci` holds the candidate indices in placement order.
 template <int FF, bool SAFE>
-__device__ __forceinline__ Px8 blend_group(int y, int x, int cnt, unsigned idx, const TileRef* list,
+__device__ __forceinline__ Px8 blend_group(int y, int x, int cnt, const int (&ci)[4], const TileRef* list,
                                            const uint16_t* __restrict__ tiles, int H, int W,
                                            const void* __restrict__ flatfields) {
   constexpr size_t ffsize = FF == MISTITCH_FF_F64 ? 8 : 4;
-  Px8 sv[3];
-  F8 sf32[FF == MISTITCH_FF_F32 ? 3 : 1];
-  D8 sf64[FF == MISTITCH_FF_F64 ? 3 : 1];
-  int lys[3], lxs[3];
+  Px8 sv[4];
+  F8 sf32[FF == MISTITCH_FF_F32 ? 4 : 1];
+  D8 sf64[FF == MISTITCH_FF_F64 ? 4 : 1];
+  int lys[4], lxs[4];
   const int64_t at = (int64_t)y * W + x;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int shift = 5 * (cnt - 1 - (q < cnt ? q : 0));  // an absent third source re-reads the first
-    const TileRef c = list[(idx >> shift) & 31u];
+  auto load = [&](int q) {
+    const TileRef c = list[ci[q]];
     lys[q] = y - c.ty;
     lxs[q] = x - c.tx;
     sv[q] = *reinterpret_cast<const Px8*>(tiles + (c.src_base + at));
@@ -398,33 +399,37 @@ __device__ __forceinline__ Px8 blend_group(int y, int x, int cnt, unsigned idx, 
       sf32[q] = *reinterpret_cast<const F8*>(reinterpret_cast<const char*>(flatfields) + (c.ff_base + at) * (int64_t)ffsize);
     if constexpr (FF == MISTITCH_FF_F64)
       sf64[q] = *reinterpret_cast<const D8*>(reinterpret_cast<const char*>(flatfields) + (c.ff_base + at) * (int64_t)ffsize);
-  }
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    MS_PIN_PX8(sv[q]);
-    if constexpr (FF == MISTITCH_FF_F32) MS_PIN_8(sf32[q]);
-    if constexpr (FF == MISTITCH_FF_F64) MS_PIN_8(sf64[q]);
+  };
+  load(0);
+  load(1);
+  if (cnt > 2) {  // corners of the tile grid only; an absent fourth source re-reads the first
+    load(2);
+    load(3);
   }
   f2 num[4], den[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) num[p] = den[p] = f2{0.0f, 0.0f};
+  auto add = [&](int q) {
+    const float wy = (float)min(lys[q] + 1, H - lys[q]);
+    const float a = (float)(lxs[q] + 1), b = (float)(W - lxs[q]);  // ramp from the left / right tile edge
+    unsigned u[8];
+    corrected8<FF, SAFE>(sv[q], sf32[FF == MISTITCH_FF_F32 ? q : 0], sf64[FF == MISTITCH_FF_F64 ? q : 0], u);
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    if (q < 2 || cnt == 3) {
-      const float wy = (float)min(lys[q] + 1, H - lys[q]);
-      const float a = (float)(lxs[q] + 1), b = (float)(W - lxs[q]);  // ramp from the left / right tile edge
-      unsigned u[8];
-      corrected8<FF, SAFE>(sv[q], sf32[FF == MISTITCH_FF_F32 ? q : 0], sf64[FF == MISTITCH_FF_F64 ? q : 0], u);
-#pragma unroll
-      for (int p = 0; p < 4; ++p) {
-        const f2 val = {(float)u[2 * p], (float)u[2 * p + 1]};
-        const f2 up = f2{a, a} + f2{(float)(2 * p), (float)(2 * p + 1)};
-        const f2 down = f2{b, b} - f2{(float)(2 * p), (float)(2 * p + 1)};
-        const f2 w = f2{wy, wy} * f2{fminf(up.x, down.x), fminf(up.y, down.y)};
-        num[p] = num[p] + w * val;
-        den[p] = den[p] + w;
-      }
+    for (int p = 0; p < 4; ++p) {
+      const f2 val = {(float)u[2 * p], (float)u[2 * p + 1]};
+      const f2 up = f2{a, a} + f2{(float)(2 * p), (float)(2 * p + 1)};
+      const f2 down = f2{b, b} - f2{(float)(2 * p), (float)(2 * p + 1)};
+      // non-positive beyond either edge of the tile: weight 0 there
+      const f2 w = f2{wy, wy} * f2{fmaxf(fminf(up.x, down.x), 0.0f), fmaxf(fminf(up.y, down.y), 0.0f)};
+      num[p] = num[p] + w * val;
+      den[p] = den[p] + w;
     }
+  };
+  add(0);
+  add(1);
+  if (cnt > 2) {
+    add(2);
+    if (cnt > 3) add(3);
   }
   Px8 o;
 #pragma unroll
@@ -441,7 +446,8 @@ __device__ __forceinline__ Px8 blend_group(int y, int x, int cnt, unsigned idx, 
 //
 // Queue entries (one 32-bit word per group that is not a plain copy):
 //   bits 0-7 group in the block row, 8-12 row in the block, 13-14 number of blended
-//   sources (0: resolve pixel by pixel), 15-29 their candidate indices, 5 bits each.
+//   sources less one (0: resolve pixel by pixel), 15-30 their candidate indices: two of 5
+//   bits, or three or four of 4 bits, the last placed in the lowest bits.
 // Blend entries fill the queue from the bottom, pixel-by-pixel entries from the top.
 template <int MODE, int FF, int GX, bool SAFE>
 __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsigned* queue_len,
@@ -507,25 +513,34 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
     unsigned idx[GX];    // touching candidates, 5 bits each, the last placed in the lowest bits
     bool bad[GX];        // some touching tile covers the group only partly or lacks a flatfield plane
     bool last_bad[GX];   // the same for the last placed touching tile alone
+    bool hard[GX];       // feather: a touching tile that no batched blend can take (see blend_group)
+    bool full[GX];       // feather: some touching tile covers all 8 pixels
 #pragma unroll
     for (int r = 0; r < GX; ++r) {
       cnt[r] = 0;
       idx[r] = 0;
-      bad[r] = last_bad[r] = false;
+      bad[r] = last_bad[r] = hard[r] = full[r] = false;
     }
     for (unsigned m = ymask; m; m &= m - 1u) {  // wave-uniform loop over the row's tiles
       const int ci = __builtin_ctz(m);
       const int tx = list[ci].tx;
       const bool not_ok = !((ffok >> ci) & 1u);
+      const int ly = y - list[ci].ty;
+      const bool edge_row = (ly == 0) | (ly == H - 1);  // a partly covering tile's load would leave the tile here
 #pragma unroll
       for (int r = 0; r < GX; ++r) {
         const int lx0 = x0 + 512 * r - tx;
         const bool touch = (unsigned)(lx0 + 7) < (unsigned)(W + 7);
-        const bool part = ((unsigned)lx0 > (unsigned)(W - 8)) | not_ok;
+        const bool cut = (unsigned)lx0 > (unsigned)(W - 8);
+        const bool part = cut | not_ok;
         idx[r] = touch ? ((idx[r] << 5) | (unsigned)ci) : idx[r];
         cnt[r] += touch ? 1 : 0;
         bad[r] = bad[r] | (touch & part);
         last_bad[r] = touch ? part : last_bad[r];
+        if constexpr (MODE == MISTITCH_FUSE_FEATHER) {
+          hard[r] = hard[r] | (touch & (not_ok | (cut & edge_row)));
+          full[r] = full[r] | (touch & !cut);
+        }
       }
     }
     Px8 v[GX];
@@ -576,10 +591,15 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
         // handled in place they would stall every wave that owns a few
         unsigned e = (unsigned)(lane + 64 * r) | ((unsigned)(y - y0) << 8);
         const bool inside = (unsigned)x <= (unsigned)(Wm - 8);
-        const bool blend = MODE == MISTITCH_FUSE_FEATHER && !generic_only && inside && !bad[r] && cnt[r] >= 2 &&
-                           cnt[r] <= 3;
+        // two sources may have any list index; three or four must all lie below 16 (4-bit fields)
+        const unsigned i5 = idx[r];
+        const bool small = ((i5 | (i5 >> 5) | (i5 >> 10) | (i5 >> 15)) & 16u) == 0;
+        const bool blend = MODE == MISTITCH_FUSE_FEATHER && !generic_only && inside && !hard[r] && full[r] &&
+                           cnt[r] >= 2 && (cnt[r] == 2 || (cnt[r] <= 4 && small));
         if (blend) {
-          e |= ((unsigned)cnt[r] << 13) | (idx[r] << 15);
+          const unsigned packed = cnt[r] == 2 ? (i5 & 0x3ffu)
+                                              : ((i5 & 15u) | ((i5 >> 1) & 0xf0u) | ((i5 >> 2) & 0xf00u) | ((i5 >> 3) & 0xf000u));
+          e |= ((unsigned)(cnt[r] - 1) << 13) | (packed << 15);
           queue[atomicAdd(&queue_len[0], 1u)] = e;
         } else {
           queue[kQueue - 1 - atomicAdd(&queue_len[1], 1u)] = e;
@@ -589,18 +609,38 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
   }
   __syncthreads();
   if constexpr (MODE == MISTITCH_FUSE_FEATHER) {
+#ifdef MS_ABL_NOBLEND
+    const unsigned n_blend = 0;
+#else
     const unsigned n_blend = queue_len[0];
+#endif
     for (unsigned i = tid; i < n_blend; i += kFuseThreads) {
       const unsigned e = queue[i];
       const int y = y0 + (int)((e >> 8) & 31u);
       uint16_t* rowp = mplane + (int64_t)y * Wm;
       const int a = (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
       const int x = 8 * (bx * (64 * GX) + (int)(e & 0xffu)) - a;
-      *reinterpret_cast<Px8*>(rowp + x) =
-          blend_group<FF, SAFE>(y, x, (int)((e >> 13) & 3u), (e >> 15) & 0x7fffu, list, tiles, H, W, flatfields);
+      const int cnt = (int)((e >> 13) & 3u) + 1;
+      const unsigned f = e >> 15;
+      int ci[4];  // placement order; absent sources repeat the first
+      if (cnt == 2) {
+        ci[0] = (int)((f >> 5) & 31u);
+        ci[1] = (int)(f & 31u);
+        ci[2] = ci[3] = ci[0];
+      } else {
+        ci[0] = (int)((f >> (4 * (cnt - 1))) & 15u);
+        ci[1] = (int)((f >> (4 * (cnt - 2))) & 15u);
+        ci[2] = (int)((f >> (4 * (cnt - 3))) & 15u);
+        ci[3] = cnt == 4 ? (int)(f & 15u) : ci[0];
+      }
+      *reinterpret_cast<Px8*>(rowp + x) = blend_group<FF, SAFE>(y, x, cnt, ci, list, tiles, H, W, flatfields);
     }
   }
+#ifdef MS_ABL_NOGENERIC
+  const unsigned n_generic = 0;
+#else
   const unsigned n_generic = queue_len[1];
+#endif
   for (unsigned i = tid; i < n_generic; i += kFuseThreads) {
     const unsigned e = queue[kQueue - 1 - i];
     const int y = y0 + (int)((e >> 8) & 31u);

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--overlap", type=float, default=0.1)
     ap.add_argument("--jitter", type=int, default=7)
+    ap.add_argument("--only", default="", help="run one variant only, e.g. feather:f32")
+    ap.add_argument("--align", type=int, default=1, help="round tile columns down to a multiple of this")
     args = ap.parse_args()
     import torch
     from image_stitcher_amd import _lib, synth
@@ -29,6 +31,7 @@ def main():
     rng = np.random.default_rng(0)
     yx = np.array([[r * pitch + rng.integers(0, args.jitter), c * pitch + rng.integers(0, args.jitter)]
                    for r in range(args.rows) for c in range(args.cols)], dtype=np.int32)
+    yx[:, 1] -= yx[:, 1] % args.align
     mh, mw = int(yx[:, 0].max()) + t, int(yx[:, 1].max()) + t
     tiles = torch.randint(0, 30000, (ch * n, t, t), dtype=torch.int16, device=dev).view(torch.uint16)
     d_yx = torch.as_tensor(np.tile(yx, (ch, 1)), dtype=torch.int32, device=dev)
@@ -38,6 +41,8 @@ def main():
     ctx = _lib.Context(0, torch.cuda.current_stream(dev).cuda_stream)
     for mode_name, mode in (("overwrite", _lib.FUSE_OVERWRITE), ("feather", _lib.FUSE_FEATHER)):
         for ff_name, ffs, fft in (("none", None, _lib.FF_NONE), ("f32", ffs32, _lib.FF_F32)):
+            if args.only and args.only != f"{mode_name}:{ff_name}":
+                continue
             def run():
                 check(lib.mistitch_fuse(ctx.handle, ptr(tiles), ch * n, t, t, t * t, ptr(d_yx), ptr(d_plane), ptr(ffs),
                                         fft, ptr(d_plane) if ffs is not None else ptr(None), ptr(mosaic), ch, mh, mw,
