@@ -380,7 +380,9 @@ __device__ __forceinline__ Px8 corrected8_packed(const Px8& v, const F8& f32, co
 // 0 * value and 0 changes neither sum); its 16-byte load then runs into the neighbouring row
 // of the same tile, which is why such a tile must not touch the group in its first or last
 // row.  `ci` holds the candidate indices in placement order.
-template <int FF, bool SAFE>
+// In overwrite mode the same loads feed a selection instead: every pixel takes the value of
+// the last placed tile that covers it (0 where none does), for 1 to 4 touching tiles.
+template <int MODE, int FF, bool SAFE>
 __device__ __forceinline__ Px8 blend_group(int y, int x, int cnt, const int (&ci)[4], const TileRef* list,
                                            const uint16_t* __restrict__ tiles, int H, int W,
                                            const void* __restrict__ flatfields) {
@@ -406,38 +408,60 @@ __device__ __forceinline__ Px8 blend_group(int y, int x, int cnt, const int (&ci
     load(2);
     load(3);
   }
-  f2 num[4], den[4];
+  if constexpr (MODE == MISTITCH_FUSE_OVERWRITE) {
+    unsigned out[8];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) num[p] = den[p] = f2{0.0f, 0.0f};
-  auto add = [&](int q) {
-    const float wy = (float)min(lys[q] + 1, H - lys[q]);
-    const float a = (float)(lxs[q] + 1), b = (float)(W - lxs[q]);  // ramp from the left / right tile edge
-    unsigned u[8];
-    corrected8<FF, SAFE>(sv[q], sf32[FF == MISTITCH_FF_F32 ? q : 0], sf64[FF == MISTITCH_FF_F64 ? q : 0], u);
+    for (int i = 0; i < 8; ++i) out[i] = 0u;
+    auto put = [&](int q) {
+      unsigned u[8];
+      corrected8<FF, SAFE>(sv[q], sf32[FF == MISTITCH_FF_F32 ? q : 0], sf64[FF == MISTITCH_FF_F64 ? q : 0], u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[i] = (unsigned)(lxs[q] + i) < (unsigned)W ? u[i] : out[i];
+    };
+    put(0);
+    if (cnt > 1) put(1);
+    if (cnt > 2) {
+      put(2);
+      if (cnt > 3) put(3);
+    }
+    Px8 o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) o.d[p] = out[2 * p] | (out[2 * p + 1] << 16);
+    return o;
+  } else {
+    f2 num[4], den[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) num[p] = den[p] = f2{0.0f, 0.0f};
+    auto add = [&](int q) {
+      const float wy = (float)min(lys[q] + 1, H - lys[q]);
+      const float a = (float)(lxs[q] + 1), b = (float)(W - lxs[q]);  // ramp from the left / right tile edge
+      unsigned u[8];
+      corrected8<FF, SAFE>(sv[q], sf32[FF == MISTITCH_FF_F32 ? q : 0], sf64[FF == MISTITCH_FF_F64 ? q : 0], u);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const f2 val = {(float)u[2 * p], (float)u[2 * p + 1]};
+        const f2 up = f2{a, a} + f2{(float)(2 * p), (float)(2 * p + 1)};
+        const f2 down = f2{b, b} - f2{(float)(2 * p), (float)(2 * p + 1)};
+        // non-positive beyond either edge of the tile: weight 0 there
+        const f2 w = f2{wy, wy} * f2{fmaxf(fminf(up.x, down.x), 0.0f), fmaxf(fminf(up.y, down.y), 0.0f)};
+        num[p] = num[p] + w * val;
+        den[p] = den[p] + w;
+      }
+    };
+    add(0);
+    add(1);
+    if (cnt > 2) {
+      add(2);
+      if (cnt > 3) add(3);
+    }
+    Px8 o;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const f2 val = {(float)u[2 * p], (float)u[2 * p + 1]};
-      const f2 up = f2{a, a} + f2{(float)(2 * p), (float)(2 * p + 1)};
-      const f2 down = f2{b, b} - f2{(float)(2 * p), (float)(2 * p + 1)};
-      // non-positive beyond either edge of the tile: weight 0 there
-      const f2 w = f2{wy, wy} * f2{fmaxf(fminf(up.x, down.x), 0.0f), fmaxf(fminf(up.y, down.y), 0.0f)};
-      num[p] = num[p] + w * val;
-      den[p] = den[p] + w;
+      const f2 t = div2_noscale(num[p], den[p]) + f2{0.5f, 0.5f};  // floor(t) by the truncating conversion: t > 0
+      o.d[p] = pack2((unsigned int)t.x, (unsigned int)t.y);
     }
-  };
-  add(0);
-  add(1);
-  if (cnt > 2) {
-    add(2);
-    if (cnt > 3) add(3);
+    return o;
   }
-  Px8 o;
-#pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    const f2 t = div2_noscale(num[p], den[p]) + f2{0.5f, 0.5f};  // floor(t) by the truncating conversion: t > 0
-    o.d[p] = pack2((unsigned int)t.x, (unsigned int)t.y);
-  }
-  return o;
 }
 
 // Work of one block.  1-D grid of 8 * gx * ceil(gy * n_planes / 8) workgroups with
@@ -513,8 +537,8 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
     unsigned idx[GX];    // touching candidates, 5 bits each, the last placed in the lowest bits
     bool bad[GX];        // some touching tile covers the group only partly or lacks a flatfield plane
     bool last_bad[GX];   // the same for the last placed touching tile alone
-    bool hard[GX];       // feather: a touching tile that no batched blend can take (see blend_group)
-    bool full[GX];       // feather: some touching tile covers all 8 pixels
+    bool hard[GX];       // a touching tile that no batched blend or selection can take (see blend_group)
+    bool full[GX];       // some touching tile covers all 8 pixels
 #pragma unroll
     for (int r = 0; r < GX; ++r) {
       cnt[r] = 0;
@@ -537,10 +561,8 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
         cnt[r] += touch ? 1 : 0;
         bad[r] = bad[r] | (touch & part);
         last_bad[r] = touch ? part : last_bad[r];
-        if constexpr (MODE == MISTITCH_FUSE_FEATHER) {
-          hard[r] = hard[r] | (touch & (not_ok | (cut & edge_row)));
-          full[r] = full[r] | (touch & !cut);
-        }
+        hard[r] = hard[r] | (touch & (not_ok | (cut & edge_row)));
+        full[r] = full[r] | (touch & !cut);
       }
     }
     Px8 v[GX];
@@ -594,10 +616,10 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
         // two sources may have any list index; three or four must all lie below 16 (4-bit fields)
         const unsigned i5 = idx[r];
         const bool small = ((i5 | (i5 >> 5) | (i5 >> 10) | (i5 >> 15)) & 16u) == 0;
-        const bool blend = MODE == MISTITCH_FUSE_FEATHER && !generic_only && inside && !hard[r] && full[r] &&
-                           cnt[r] >= 2 && (cnt[r] == 2 || (cnt[r] <= 4 && small));
-        if (blend) {
-          const unsigned packed = cnt[r] == 2 ? (i5 & 0x3ffu)
+        const bool batched = !generic_only && inside && !hard[r] && (cnt[r] <= 2 || (cnt[r] <= 4 && small)) &&
+                             (MODE == MISTITCH_FUSE_FEATHER ? (full[r] && cnt[r] >= 2) : cnt[r] >= 1);
+        if (batched) {
+          const unsigned packed = cnt[r] <= 2 ? (i5 & 0x3ffu)
                                               : ((i5 & 15u) | ((i5 >> 1) & 0xf0u) | ((i5 >> 2) & 0xf00u) | ((i5 >> 3) & 0xf000u));
           e |= ((unsigned)(cnt[r] - 1) << 13) | (packed << 15);
           queue[atomicAdd(&queue_len[0], 1u)] = e;
@@ -608,12 +630,8 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
     }
   }
   __syncthreads();
-  if constexpr (MODE == MISTITCH_FUSE_FEATHER) {
-#ifdef MS_ABL_NOBLEND
-    const unsigned n_blend = 0;
-#else
+  {
     const unsigned n_blend = queue_len[0];
-#endif
     for (unsigned i = tid; i < n_blend; i += kFuseThreads) {
       const unsigned e = queue[i];
       const int y = y0 + (int)((e >> 8) & 31u);
@@ -623,9 +641,9 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
       const int cnt = (int)((e >> 13) & 3u) + 1;
       const unsigned f = e >> 15;
       int ci[4];  // placement order; absent sources repeat the first
-      if (cnt == 2) {
-        ci[0] = (int)((f >> 5) & 31u);
+      if (cnt <= 2) {
         ci[1] = (int)(f & 31u);
+        ci[0] = cnt == 2 ? (int)((f >> 5) & 31u) : ci[1];
         ci[2] = ci[3] = ci[0];
       } else {
         ci[0] = (int)((f >> (4 * (cnt - 1))) & 15u);
@@ -633,14 +651,10 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
         ci[2] = (int)((f >> (4 * (cnt - 3))) & 15u);
         ci[3] = cnt == 4 ? (int)(f & 15u) : ci[0];
       }
-      *reinterpret_cast<Px8*>(rowp + x) = blend_group<FF, SAFE>(y, x, cnt, ci, list, tiles, H, W, flatfields);
+      *reinterpret_cast<Px8*>(rowp + x) = blend_group<MODE, FF, SAFE>(y, x, cnt, ci, list, tiles, H, W, flatfields);
     }
   }
-#ifdef MS_ABL_NOGENERIC
-  const unsigned n_generic = 0;
-#else
   const unsigned n_generic = queue_len[1];
-#endif
   for (unsigned i = tid; i < n_generic; i += kFuseThreads) {
     const unsigned e = queue[kQueue - 1 - i];
     const int y = y0 + (int)((e >> 8) & 31u);
