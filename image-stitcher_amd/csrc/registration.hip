@@ -48,7 +48,7 @@ constexpr int kNumCand = 32;    // 2 peaks x 16 signed interpretations
 constexpr int kNccChunks = 8;   // workgroups cooperating on one candidate
 constexpr int kCandSlots = kNumCand + 1;  // the last slot holds the subpixel estimate's rounded shift (flag 1 when unused)
 constexpr int kUpsMax = 160;    // largest upsampled region side (ceil(1.5 * upsample factor))
-constexpr int kUpsRows = 15;    // upsampled rows per block of the second stage
+constexpr int kUpsRows = 80;    // upsampled rows per block of the second stage (five 16-row tiles)
 
 struct PairDesc {
   const uint16_t* a;  // canonical strip of the first tile
@@ -208,7 +208,8 @@ __device__ __forceinline__ Peak block_argmax(Peak mine, Peak* red /*[kThreads/64
 }
 
 // Block-wide argmax where the smallest key wins among equal values; result valid in every thread.
-__device__ __forceinline__ Peak block_argmax_first(Peak mine, Peak* red /*[kThreads/64]*/) {
+template <int NW = kThreads / 64>
+__device__ __forceinline__ Peak block_argmax_first(Peak mine, Peak* red /*[NW]*/) {
   mine = wave_best_peak(mine, first_better);
   const int wave = threadIdx.x >> 6;
   __syncthreads();
@@ -216,7 +217,7 @@ __device__ __forceinline__ Peak block_argmax_first(Peak mine, Peak* red /*[kThre
   __syncthreads();
   Peak best = red[0];
 #pragma unroll
-  for (int w = 1; w < kThreads / 64; ++w) {
+  for (int w = 1; w < NW; ++w) {
     Peak o = red[w];
     if (first_better(o.val, o.key, best.val, best.key)) best = o;
   }
@@ -1193,14 +1194,17 @@ struct KappaEntry {
 // run as v_mfma_f64_16x16x4_f64 steps: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15];
 // result register g of lane l is C[(l >> 4) + 4 g][l & 15].  A step covers two kk.
 // grid (n_units, pairs_in_pass); a wave owns up to kUpsTilesPerWave 16-row tiles of u.
-constexpr int kUpsTilesPerWave = 3;  // 4 waves x 3 tiles x 16 rows >= kUpsMax
+constexpr int kUpsThreads = 320;     // five waves: the ten 16-row (or 16-column) tiles of kUpsMax split evenly
+constexpr int kUpsTilesPerWave = 2;  // 5 waves x 2 tiles x 16 rows >= kUpsMax
+static_assert((kUpsThreads / 64) * kUpsTilesPerWave * 16 >= kUpsMax, "tiles must cover the upsampled region");
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 template <typename T>
-__global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, const int8_t* status, int pair0, int S,
+__global__ __launch_bounds__(kUpsThreads) void k_ups_short(const PairDesc* desc, const int8_t* status, int pair0, int S,
                                                         int L, int want_transposed, FftPlanDev planS,
                                                         const CpsUnit* __restrict__ units,
-                                                        const uint16_t* __restrict__ pos2stored, int n_stored,
+                                                        const uint16_t* __restrict__ pos2stored,
+                                                        const uint16_t* __restrict__ stored2kappa, int n_stored,
                                                         const cx<T>* __restrict__ rslabs,
                                                         const UpsState* __restrict__ ups, int n_up, double uf,
                                                         double2* __restrict__ T1, double2* __restrict__ Nq) {
@@ -1223,7 +1227,9 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
     const cx<T> v = Rs[(pos / kSlab) * sp + pos % kSlab];
     Nq[(int64_t)blockIdx.y * n_stored + pos2stored[pos]] = mk<double>((double)v.x, (double)v.y);
   }
-  double2* t1 = T1 + (int64_t)blockIdx.y * n_up * n_stored;
+  // results go to T1[|frequency| of the column][u]: what the second stage reads is then contiguous, and
+  // the 16 displacements a lane group holds for one column are adjacent here
+  double2* t1 = T1 + (int64_t)blockIdx.y * n_stored * kUpsMax;
   // lane roles inside a step
   const int i = lane & 15, k = lane >> 4;  // A: row i, k index; B: k index, column i
   const int part = k & 1, kk_off = k >> 1;
@@ -1236,7 +1242,7 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
     if (pos % kSlab == 0 && pos + kSlab <= end && (S & 1) == 0) {
       __syncthreads();  // the previous slab has been consumed
       const cx<T>* slab = Rs + (pos / kSlab) * sp;
-      for (int e = tid; e < S * kSlab; e += kThreads) {
+      for (int e = tid; e < S * kSlab; e += kUpsThreads) {
         const cx<T> v = slab[e];
         rows[2 * e] = (double)v.x;
         rows[2 * e + 1] = (double)v.y;
@@ -1266,14 +1272,14 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
         }
       }
       const int c = i >> 1, o = i & 1;
-      const int col = pos2stored[pos + c];
+      const int kap = stored2kappa[pos2stored[pos + c]];  // 0xffff: the second stored column of a conjugate pair, unused
 #pragma unroll
       for (int t = 0; t < kUpsTilesPerWave; ++t) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int u = (wave * kUpsTilesPerWave + t) * 16 + k + 4 * g;
-          if (u < n_up) {
-            double* dst = reinterpret_cast<double*>(t1 + (int64_t)u * n_stored + col);
+          if (u < n_up && kap != 0xffff) {
+            double* dst = reinterpret_cast<double*>(t1 + (int64_t)kap * kUpsMax + u);
             dst[o] = acc[t][g];
           }
         }
@@ -1295,26 +1301,109 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
           acc.y += (double)r.x * ww.y + (double)r.y * ww.x;
           ww = cmul(ww, step);
         }
-        t1[(int64_t)tid * n_stored + pos2stored[pos]] = acc;
+        const int kap = stored2kappa[pos2stored[pos]];
+        if (kap != 0xffff) t1[(int64_t)kap * kUpsMax + tid] = acc;
       }
       pos += 1;
     }
   }
 }
 
-// grid (ceil(n_up / kUpsRows), pairs_in_pass); thread ul owns one long-axis displacement
-// and kUpsRows short-axis ones.  Emits the block's largest |CC|^2, first in the
-// row-major order of the IMAGE orientation on ties.
+// Nyquist-row sums of the second stage: for every long-axis displacement ul,
+//   g(ul) = g1 + conj(g2),  g1 = sum over stored columns of negative frequency of V w,  g2 = the same for
+//   positive ones, V = the column's Nyquist-row value (conjugated where the stored frequency is negative),
+//   w = exp(i theta_ul kappa).  grid (pairs_in_pass); out[pair][ul] = (Re g, Im g).
+constexpr int kNyqParts = 4;  // the kappa range is cut into four, one part per 256 lanes
+__global__ __launch_bounds__(kNyqParts * 256) void k_ups_nyquist(const PairDesc* desc, const int8_t* status, int pair0,
+                                                                 int S, int L, int want_transposed,
+                                                                 const KappaEntry* __restrict__ kappa, int n_stored,
+                                                                 const double2* __restrict__ Nq,
+                                                                 const UpsState* __restrict__ ups, int n_up, double uf,
+                                                                 double2* __restrict__ gout) {
+  constexpr int kMaxKappa = 4096 / 2 + 1;
+  __shared__ double2 sV[kMaxKappa];
+  __shared__ int8_t sSign[kMaxKappa];
+  __shared__ double2 sG[kNyqParts][kUpsMax];
+  const int p = pair0 + blockIdx.x;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  const UpsState st = ups[p];
+  if (!st.valid) return;
+  const int tid = threadIdx.x, ul = tid & 255, part = tid >> 8;
+  const double2* nq = Nq + (int64_t)blockIdx.x * n_stored;
+  const int n_kappa = L / 2 + 1;
+  for (int e = tid; e < n_kappa; e += kNyqParts * 256) {
+    const KappaEntry ke = kappa[e];
+    double2 v = nq[ke.stored];
+    if (ke.sign < 0) v.y = -v.y;
+    if (ke.self) v = mk<double>(0.0, 0.0);  // self-conjugate columns have no partner to correct
+    sV[e] = v;
+    sSign[e] = ke.sign;
+  }
+  __syncthreads();
+  const int per = (n_kappa + kNyqParts - 1) / kNyqParts;
+  const int k_begin = part * per, k_end = min(n_kappa, k_begin + per);
+  if (ul < n_up) {
+    const double delta_l = (double)st.shift_l + ((double)ul - (double)(n_up / 2)) / uf;
+    const double theta = 2.0 * 3.14159265358979323846 * delta_l / (double)L;
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    const double2 step = mk<double>(cs, sn);
+    sincos(theta * (double)k_begin, &sn, &cs);
+    double2 w = mk<double>(cs, sn), g1 = mk<double>(0.0, 0.0), g2 = mk<double>(0.0, 0.0);
+    for (int j = k_begin; j < k_end; ++j) {
+      const double2 vw = cmul(sV[j], w);
+      if (sSign[j] < 0) {
+        g1.x += vw.x;
+        g1.y += vw.y;
+      } else {
+        g2.x += vw.x;
+        g2.y += vw.y;
+      }
+      w = cmul(w, step);
+    }
+    sG[part][ul] = mk<double>(g1.x + g2.x, g1.y - g2.y);
+  }
+  __syncthreads();
+  if (part == 0 && ul < n_up) {
+    double2 g = sG[0][ul];
+#pragma unroll
+    for (int q = 1; q < kNyqParts; ++q) {
+      g.x += sG[q][ul].x;
+      g.y += sG[q][ul].y;
+    }
+    gout[(int64_t)blockIdx.x * kUpsMax + ul] = g;
+  }
+}
+
+// Second stage on the matrix cores.  With Y[us][kappa] the first-stage value of the stored column of
+// |frequency| kappa (conjugated where that column's frequency is negative, doubled unless it is its own
+// partner), Re CC[us][ul] = sum_kappa Re(Y w), w = exp(i theta_ul kappa), is a real product C = A B with
+//   A[us][2 kappa + p] = p ? -Im Y : Re Y        (staged in LDS, 64 kappa at a time)
+//   B[2 kappa + p][ul] = p ? Im w : Re w         (generated: one rotor per lane and column tile)
+// run as v_mfma_f64_16x16x4_f64 steps of two kappa (lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15];
+// result register g of lane l is C[(l >> 4) + 4 g][l & 15]).  The imaginary part exists only for the two
+// self-conjugate columns and is added, with the Nyquist-row term, when the magnitudes are formed.
+// grid (ceil(n_up / kUpsRows), pairs_in_pass): a workgroup owns kUpsRows = 80 short-axis displacements
+// (five row tiles) and all ten column tiles.  Emits the block's largest
+// |CC|^2, first in the row-major order of the IMAGE orientation on ties.
+// The 10 x 5 result tiles of a workgroup are dealt to its four waves as evenly as a shared rotor allows:
+// wave w takes column tiles 2w and 2w + 1 with all five row tiles, and of column tile 8 + (w & 1) the row
+// tiles {0, 1, 2} (w < 2) or {3, 4}: 13 or 12 products per step and three rotor updates (the rotors are
+// float64 vector work, which competes with the float64 matrix instructions for the same units).
 __global__ __launch_bounds__(kThreads) void k_ups_long(const PairDesc* desc, const int8_t* status, int pair0, int S, int L,
                                                        int want_transposed, const KappaEntry* __restrict__ kappa,
                                                        int n_stored, const double2* __restrict__ T1,
-                                                       const double2* __restrict__ Nq,
+                                                       const double2* __restrict__ gin,
                                                        const UpsState* __restrict__ ups, int n_up, double uf,
                                                        Peak* partial_ups, int n_row_blocks) {
-  constexpr int kChunk = 64;
-  __shared__ double2 sY[kUpsRows][kChunk];  // stored column values, conjugated where the stored frequency is negative, times 2 unless self
-  __shared__ double2 sV[kChunk];            // Nyquist-row values, conjugated likewise
-  __shared__ int8_t sSign[kChunk], sSelf[kChunk];
+  constexpr int kChunk = 32;                 // kappa per staging round
+  constexpr int kRowTiles = kUpsRows / 16;   // 5
+  static_assert(kRowTiles == 5 && kUpsMax <= 160 && kThreads == 256, "tile assignment below");
+  __shared__ double sA[kChunk][kUpsRows][2];  // (Re Y, -Im Y)
+  __shared__ double2 sSelf[2][kUpsRows];      // Y of the self-conjugate columns kappa = 0 and kappa = L / 2
+  __shared__ KappaEntry sK[4096 / 2 + 1];
   __shared__ Peak red[kThreads / 64];
   const int p = pair0 + blockIdx.y;
   if (status[p] != MISTITCH_PAIR_OK) return;
@@ -1322,89 +1411,139 @@ __global__ __launch_bounds__(kThreads) void k_ups_long(const PairDesc* desc, con
   if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
   const UpsState st = ups[p];
   if (!st.valid) return;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int us0 = blockIdx.x * kUpsRows;
   const int nrows = min(kUpsRows, n_up - us0);
-  const double2* t1 = T1 + (int64_t)blockIdx.y * n_up * n_stored;
-  const double2* nq = Nq + (int64_t)blockIdx.y * n_stored;
-  const int ul = tid;
-  const double delta_l = (double)st.shift_l + ((double)ul - (double)(n_up / 2)) / uf;
-  const double theta = 2.0 * 3.14159265358979323846 * delta_l / (double)L;
-  double sn, cs;
-  sincos(theta, &sn, &cs);
-  const double2 step = mk<double>(cs, sn);
-  double2 w = mk<double>(1.0, 0.0);  // exp(i theta kappa)
-  double re[kUpsRows], im[kUpsRows];
-#pragma unroll
-  for (int r = 0; r < kUpsRows; ++r) re[r] = im[r] = 0.0;
-  double2 g1 = mk<double>(0.0, 0.0), g2 = mk<double>(0.0, 0.0);
+  const double2* t1 = T1 + (int64_t)blockIdx.y * n_stored * kUpsMax;  // [kappa][u]
   const int n_kappa = L / 2 + 1;
-  for (int k0 = 0; k0 < n_kappa; k0 += kChunk) {
-    const int nk = min(kChunk, n_kappa - k0);
-    __syncthreads();
-    for (int e = tid; e < nk * (kUpsRows + 1); e += kThreads) {
-      const int j = e % nk, r = e / nk;
-      const KappaEntry ke = kappa[k0 + j];
-      if (r < kUpsRows) {
-        double2 x = mk<double>(0.0, 0.0);
-        if (r < nrows) x = t1[(int64_t)(us0 + r) * n_stored + ke.stored];
+  const int i = lane & 15, k = lane >> 4;
+  const int part = k & 1, kk_off = k >> 1;
+  const bool low = wave < 2;  // which row tiles of the shared column tile this wave takes
+  const int col_tile[3] = {2 * wave, 2 * wave + 1, 8 + (wave & 1)};
+  // rotors of this lane's column in each of the wave's column tiles
+  double2 w[3], step2[3];
+  d4 acc[2][kRowTiles], acc_x[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int ul = col_tile[t] * 16 + i;
+    const double delta_l = (double)st.shift_l + ((double)ul - (double)(n_up / 2)) / uf;
+    const double theta = 2.0 * 3.14159265358979323846 * delta_l / (double)L;
+    double sn, cs;
+    sincos(theta * (double)kk_off, &sn, &cs);
+    w[t] = mk<double>(cs, sn);
+    sincos(2.0 * theta, &sn, &cs);
+    step2[t] = mk<double>(cs, sn);
+    acc_x[t] = d4{0.0, 0.0, 0.0, 0.0};
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int a = 0; a < kRowTiles; ++a) acc[t][a] = d4{0.0, 0.0, 0.0, 0.0};
+  // staging: element e of a round is (kappa j = e / kUpsRows, row r = e % kUpsRows)
+  constexpr int kPer = kChunk * kUpsRows / kThreads;  // 10 elements per lane and round
+  static_assert(kChunk * kUpsRows % kThreads == 0 && kChunk % 2 == 0, "staging pattern");
+  // The column table sits in LDS so that the loads of the next round can be issued (into registers)
+  // before the products of this round and completed after them; conjugation and scaling wait
+  // until the values are written to LDS.
+  for (int e = tid; e < n_kappa; e += kThreads) sK[e] = kappa[e];
+  if (tid < 2 * kUpsRows) sSelf[tid / kUpsRows][tid % kUpsRows] = mk<double>(0.0, 0.0);
+  __syncthreads();
+  double2 pre[kPer];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int e = tid + q * kThreads, j = e / kUpsRows, r = e - j * kUpsRows;
+      const int kap = min(k0 + j, n_kappa - 1);
+      pre[q] = t1[(int64_t)kap * kUpsMax + us0 + min(r, nrows - 1)];
+    }
+  };
+  auto stage = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+      const int e = tid + q * kThreads, j = e / kUpsRows, r = e - j * kUpsRows;
+      const int kap = k0 + j;
+      double2 x = mk<double>(0.0, 0.0);
+      if (kap < n_kappa && r < nrows) {
+        const KappaEntry ke = sK[kap];
+        x = pre[q];
         if (ke.sign < 0) x.y = -x.y;
-        if (!ke.self) {
+        if (ke.self) {
+          const double sgn = ke.sign < 0 ? -1.0 : 1.0;  // Im(Y w) carries the sign of the stored frequency
+          sSelf[kap == 0 ? 0 : 1][r] = mk<double>(sgn * x.x, sgn * x.y);
+        } else {
           x.x *= 2.0;
           x.y *= 2.0;
         }
-        sY[r][j] = x;
-      } else {
-        double2 v = nq[ke.stored];
-        if (ke.sign < 0) v.y = -v.y;
-        sV[j] = v;
-        sSign[j] = ke.sign;
-        sSelf[j] = ke.self;
       }
+      sA[j][r][0] = x.x;
+      sA[j][r][1] = -x.y;
     }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < n_kappa; k0 += kChunk) {
+    __syncthreads();  // the previous round has been consumed
+    stage(k0);
     __syncthreads();
-    if ((tid & ~63) >= n_up) continue;  // a wave without displacements only helps staging
-    for (int j = 0; j < nk; ++j) {
-      if (!sSelf[j]) {
+    if (k0 + kChunk < n_kappa) fetch(k0 + kChunk);  // in flight during the products
+    const int nsteps = (min(kChunk, n_kappa - k0) + 1) / 2;
+    double nxt[kRowTiles];  // the next step's operands are read from LDS while this step's products run
 #pragma unroll
-        for (int r = 0; r < kUpsRows; ++r) re[r] += sY[r][j].x * w.x - sY[r][j].y * w.y;
-        const double2 vw = cmul(sV[j], w);
-        if (sSign[j] < 0) {
-          g1.x += vw.x;
-          g1.y += vw.y;
-        } else {
-          g2.x += vw.x;
-          g2.y += vw.y;
-        }
-      } else {
-        // X e for a self-conjugate column: real part as above, imaginary part with the sign of the stored frequency
-        const double sgn = sSign[j] < 0 ? -1.0 : 1.0;
+    for (int a = 0; a < kRowTiles; ++a) nxt[a] = sA[kk_off][16 * a + i][part];
+    for (int sidx = 0; sidx < nsteps; ++sidx) {
+      double av[kRowTiles];
 #pragma unroll
-        for (int r = 0; r < kUpsRows; ++r) {
-          re[r] += sY[r][j].x * w.x - sY[r][j].y * w.y;
-          im[r] += sgn * (sY[r][j].x * w.y + sY[r][j].y * w.x);
-        }
+      for (int a = 0; a < kRowTiles; ++a) av[a] = nxt[a];
+      const int srow = min(2 * (sidx + 1), kChunk - 2) + kk_off;
+#pragma unroll
+      for (int a = 0; a < kRowTiles; ++a) nxt[a] = sA[srow][16 * a + i][part];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {  // columns past n_up are computed too (branch-free) and not used
+        const double bv = part ? w[t].y : w[t].x;
+#pragma unroll
+        for (int a = 0; a < kRowTiles; ++a) acc[t][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv, acc[t][a], 0, 0, 0);
+        w[t] = cmul(w[t], step2[t]);
       }
-      w = cmul(w, step);
+      const double bx = part ? w[2].y : w[2].x;
+      acc_x[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(low ? av[0] : av[3], bx, acc_x[0], 0, 0, 0);
+      acc_x[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(low ? av[1] : av[4], bx, acc_x[1], 0, 0, 0);
+      if (low) acc_x[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bx, acc_x[2], 0, 0, 0);
+      w[2] = cmul(w[2], step2[2]);
     }
   }
-  // Nyquist-row term: -2i sin(pi ds) (g1 + conj(g2))
-  const double gx = g1.x + g2.x, gy = g1.y - g2.y;
+  __syncthreads();  // sSelf is complete
   Peak mine{-INFINITY, -1, -1};
-  if (ul < n_up) {
+  const double2* g = gin + (int64_t)blockIdx.y * kUpsMax;
+  // one result tile: columns ct * 16 + (lane & 15), rows rt * 16 + (lane >> 4) + 4 q
+  auto finish = [&](int ct, int rt, const d4& c) {
+    const int ul = ct * 16 + i;
+    if (ul >= n_up) return;
+    const double delta_l = (double)st.shift_l + ((double)ul - (double)(n_up / 2)) / uf;
+    double sn, cs;
+    sincospi(delta_l, &sn, &cs);  // w at kappa = L / 2 (kappa = 0: w = 1)
+    const double2 gv = g[ul];
 #pragma unroll
-    for (int r = 0; r < kUpsRows; ++r) {
+    for (int q = 0; q < 4; ++q) {
+      const int r = 16 * rt + k + 4 * q;
       if (r < nrows) {
         const int us = us0 + r;
+        const double2 y0 = sSelf[0][r], yh = sSelf[1][r];
+        const double im = y0.y + (yh.x * sn + yh.y * cs);
         const double delta_s = (double)st.shift_s + ((double)us - (double)(n_up / 2)) / uf;
         const double s2 = 2.0 * sinpi(delta_s);
-        const double cr = re[r] + s2 * gy, ci = im[r] - s2 * gx;
+        const double cr = c[q] + s2 * gv.y, ci = im - s2 * gv.x;
         const double mag2 = cr * cr + ci * ci;
         const int key = d.transposed ? ul * n_up + us : us * n_up + ul;
         if (first_better(mag2, key, mine.val, mine.key)) mine = Peak{mag2, key, 0};
       }
     }
-  }
+  };
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int a = 0; a < kRowTiles; ++a) finish(col_tile[t], a, acc[t][a]);
+  finish(col_tile[2], low ? 0 : 3, acc_x[0]);
+  finish(col_tile[2], low ? 1 : 4, acc_x[1]);
+  if (low) finish(col_tile[2], 2, acc_x[2]);
   const Peak best = block_argmax_first(mine, red);
   if (tid == 0) partial_ups[(int64_t)blockIdx.y * n_row_blocks + blockIdx.x] = best;
 }
@@ -1977,6 +2116,7 @@ struct ShapeCfg {
   int n_stored;
   const uint16_t* pos2stored;  // device: position -> index in stored_pos (0xffff: not stored)
   const KappaEntry* kappa;     // device: the stored column of every |frequency| 0 .. L/2 (subpixel stage)
+  const uint16_t* stored2kappa;  // device: stored column -> its |frequency| (0xffff: not the column that represents it)
   int NF_fwd;  // lines per k_fft_long_fwd block
   int NF_inv;  // line pairs per k_fft_long_inv block
   size_t lds_fwd, lds_cps, lds_inv;
@@ -2040,16 +2180,19 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
       MS_REQUIRE(k.stored != 0xffff, MISTITCH_ERR_UNSUPPORTED, "a conjugate pair of columns is not stored (L = %d)", L);
     const size_t ub = units.size() * sizeof(CpsUnit), sb = stored_pos.size() * sizeof(uint16_t);
     const size_t ub_pad = (ub + 15) / 16 * 16, sb_pad = (sb + 15) / 16 * 16, pb = ((size_t)L * 2 + 15) / 16 * 16;
-    const size_t kb = kappa.size() * sizeof(KappaEntry);
+    const size_t kb = (kappa.size() * sizeof(KappaEntry) + 15) / 16 * 16;
+    std::vector<uint16_t> s2k(stored_pos.size(), 0xffff);
+    for (size_t a = 0; a < kappa.size(); ++a) s2k[kappa[a].stored] = (uint16_t)a;
     void* blob = nullptr;
-    MS_HIP(hipMalloc(&blob, ub_pad + 2 * sb_pad + pb + kb));
+    MS_HIP(hipMalloc(&blob, ub_pad + 2 * sb_pad + pb + kb + sb_pad));
     ctx->shape_allocs.push_back(blob);
     char* base = reinterpret_cast<char*>(blob);
     MS_HIP(hipMemcpy(base, units.data(), ub, hipMemcpyHostToDevice));
     MS_HIP(hipMemcpy(base + ub_pad, stored_pos.data(), sb, hipMemcpyHostToDevice));
     MS_HIP(hipMemcpy(base + ub_pad + sb_pad, mirror_fill.data(), sb, hipMemcpyHostToDevice));
     MS_HIP(hipMemcpy(base + ub_pad + 2 * sb_pad, pos2stored.data(), (size_t)L * 2, hipMemcpyHostToDevice));
-    MS_HIP(hipMemcpy(base + ub_pad + 2 * sb_pad + pb, kappa.data(), kb, hipMemcpyHostToDevice));
+    MS_HIP(hipMemcpy(base + ub_pad + 2 * sb_pad + pb, kappa.data(), kappa.size() * sizeof(KappaEntry), hipMemcpyHostToDevice));
+    MS_HIP(hipMemcpy(base + ub_pad + 2 * sb_pad + pb + kb, s2k.data(), sb, hipMemcpyHostToDevice));
     cfg->units = reinterpret_cast<const CpsUnit*>(base);
     cfg->n_units = (int)units.size();
     cfg->stored_pos = reinterpret_cast<const uint16_t*>(base + ub_pad);
@@ -2057,6 +2200,7 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
     cfg->n_stored = (int)stored_pos.size();
     cfg->pos2stored = reinterpret_cast<const uint16_t*>(base + ub_pad + 2 * sb_pad);
     cfg->kappa = reinterpret_cast<const KappaEntry*>(base + ub_pad + 2 * sb_pad + pb);
+    cfg->stored2kappa = reinterpret_cast<const uint16_t*>(base + ub_pad + 2 * sb_pad + pb + kb);
   }
   const size_t lb = f64 ? line_bytes<double>(L) : line_bytes<float>(L);
   int nf = (int)(kLdsBudget / lb);
@@ -2251,7 +2395,8 @@ struct RegWorkspace {
   Peak* partial_ups = nullptr;    // [chunk][n_row_blocks]
   int n_row_blocks = 0;
   double2* nq = nullptr;          // [chunk][n_stored_max]
-  double2* t1 = nullptr;          // [chunk][n_up][n_stored_max]
+  double2* gxy = nullptr;         // [chunk][kUpsMax] Nyquist-row sums per long-axis displacement
+  double2* t1 = nullptr;          // [chunk][n_stored_max][kUpsMax]: first-stage results by |frequency| and displacement
   int n_stored_max = 0;
 };
 
@@ -2267,9 +2412,10 @@ static int reserve_subpixel(mistitch_ctx* ctx, int n_pairs, int chunk, int abs_s
   const size_t b_abs = pad((size_t)chunk * abs_stride * sizeof(Peak));
   const size_t b_pu = pad((size_t)chunk * n_row_blocks * sizeof(Peak));
   const size_t b_nq = pad((size_t)chunk * n_stored_max * sizeof(double2));
-  const size_t b_t1 = pad((size_t)chunk * n_up * n_stored_max * sizeof(double2));
+  const size_t b_g = pad((size_t)chunk * kUpsMax * sizeof(double2));
+  const size_t b_t1 = pad((size_t)chunk * kUpsMax * n_stored_max * sizeof(double2));
   int rc;
-  if ((rc = ctx->ups.reserve(b_ups + b_abs + b_pu + b_nq + b_t1))) return rc;
+  if ((rc = ctx->ups.reserve(b_ups + b_abs + b_pu + b_nq + b_g + b_t1))) return rc;
   char* base = reinterpret_cast<char*>(ctx->ups.ptr);
   ws->n_up = n_up;
   ws->uf = (double)uf;
@@ -2279,7 +2425,8 @@ static int reserve_subpixel(mistitch_ctx* ctx, int n_pairs, int chunk, int abs_s
   ws->partial_ups = reinterpret_cast<Peak*>(base + b_ups + b_abs);
   ws->n_row_blocks = n_row_blocks;
   ws->nq = reinterpret_cast<double2*>(base + b_ups + b_abs + b_pu);
-  ws->t1 = reinterpret_cast<double2*>(base + b_ups + b_abs + b_pu + b_nq);
+  ws->gxy = reinterpret_cast<double2*>(base + b_ups + b_abs + b_pu + b_nq);
+  ws->t1 = reinterpret_cast<double2*>(base + b_ups + b_abs + b_pu + b_nq + b_g);
   ws->n_stored_max = n_stored_max;
   return MISTITCH_OK;
 }
@@ -2343,11 +2490,14 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
               want_transposed, ws.partial_abs, ws.abs_stride, nblk, ws.ups);
     const size_t lds_ups = (size_t)cfg.S * 2 * kSlab * sizeof(double);
     if ((rc = allow_lds(ctx, k_ups_short<T>, lds_ups))) return rc;
-    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T>), dim3(cfg.n_units, n), dim3(kThreads), lds_ups, ws.desc, status, pair0, cfg.S,
-              cfg.L, want_transposed, cfg.planS, cfg.units, cfg.pos2stored, ws.n_stored_max, slabs, ws.ups, ws.n_up, ws.uf,
+    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T>), dim3(cfg.n_units, n), dim3(kUpsThreads), lds_ups, ws.desc, status, pair0, cfg.S,
+              cfg.L, want_transposed, cfg.planS, cfg.units, cfg.pos2stored, cfg.stored2kappa, ws.n_stored_max, slabs, ws.ups,
+              ws.n_up, ws.uf,
               ws.t1, ws.nq);
+    MS_LAUNCH(ctx, "k_ups_nyquist", k_ups_nyquist, dim3(n), dim3(kNyqParts * 256), 0, ws.desc, status, pair0, cfg.S, cfg.L,
+              want_transposed, cfg.kappa, ws.n_stored_max, ws.nq, ws.ups, ws.n_up, ws.uf, ws.gxy);
     MS_LAUNCH(ctx, "k_ups_long", k_ups_long, dim3(ws.n_row_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S, cfg.L,
-              want_transposed, cfg.kappa, ws.n_stored_max, ws.t1, ws.nq, ws.ups, ws.n_up, ws.uf, ws.partial_ups,
+              want_transposed, cfg.kappa, ws.n_stored_max, ws.t1, ws.gxy, ws.ups, ws.n_up, ws.uf, ws.partial_ups,
               ws.n_row_blocks);
   }
   MS_HIP(hipGetLastError());
