@@ -1180,6 +1180,12 @@ __global__ __launch_bounds__(kThreads) void k_ups_coarse(const PairDesc* desc, c
   }
 }
 
+// One rotor step w * s with fused multiply-adds (four instead of six float64 operations: the rotors
+// share the float64 units with the matrix instructions they feed).
+__device__ __forceinline__ double2 rotate(double2 w, double2 s) {
+  return mk<double>(__builtin_fma(w.x, s.x, -(w.y * s.y)), __builtin_fma(w.x, s.y, w.y * s.x));
+}
+
 struct KappaEntry {
   uint16_t stored;  // index into the stored-position list of the column with |kl| = kappa
   int8_t sign;      // +1: its signed frequency is +kappa, -1: -kappa
@@ -1193,23 +1199,24 @@ struct KappaEntry {
 //   C[u][2 c + o]        = o ? Im X : Re X
 // run as v_mfma_f64_16x16x4_f64 steps: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15];
 // result register g of lane l is C[(l >> 4) + 4 g][l & 15].  A step covers two kk.
-// grid (n_units, pairs_in_pass); a wave owns up to kUpsTilesPerWave 16-row tiles of u.
-constexpr int kUpsThreads = 320;     // five waves: the ten 16-row (or 16-column) tiles of kUpsMax split evenly
-constexpr int kUpsTilesPerWave = 2;  // 5 waves x 2 tiles x 16 rows >= kUpsMax
-static_assert((kUpsThreads / 64) * kUpsTilesPerWave * 16 >= kUpsMax, "tiles must cover the upsampled region");
+// grid (ceil(n_slabs / NS), pairs_in_pass), four waves.  A workgroup holds NS slabs in LDS.  Float64 vector
+// work (the rotor updates) and the float64 matrix instructions compete for the same units, so a rotor has
+// to serve several products: wave w takes the displacement tiles 2w and 2w + 1 against all NS slabs and tile
+// 8 + (w & 1) against half of them (the lower half for w < 2), three rotor updates for 5 NS / 2 products.
 typedef double d4 __attribute__((ext_vector_type(4)));
+static_assert(kUpsMax <= 160, "ten 16-row tiles cover the upsampled region");
 
-template <typename T>
-__global__ __launch_bounds__(kUpsThreads) void k_ups_short(const PairDesc* desc, const int8_t* status, int pair0, int S,
-                                                        int L, int want_transposed, FftPlanDev planS,
-                                                        const CpsUnit* __restrict__ units,
+template <typename T, int NS>
+__global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, const int8_t* status, int pair0, int S,
+                                                        int L, int want_transposed,
+                                                        const uint16_t* __restrict__ slab_pos, int n_slabs,
                                                         const uint16_t* __restrict__ pos2stored,
                                                         const uint16_t* __restrict__ stored2kappa, int n_stored,
                                                         const cx<T>* __restrict__ rslabs,
                                                         const UpsState* __restrict__ ups, int n_up, double uf,
                                                         double2* __restrict__ T1, double2* __restrict__ Nq) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* rows = reinterpret_cast<double*>(smem_raw);  // [S][2 * kSlab]: one slab, rows in ascending signed frequency
+  double* rows = reinterpret_cast<double*>(smem_raw);  // [NS][S][2 * kSlab], rows in ascending signed frequency
   const int p = pair0 + blockIdx.y;
   if (status[p] != MISTITCH_PAIR_OK) return;
   {
@@ -1218,15 +1225,43 @@ __global__ __launch_bounds__(kUpsThreads) void k_ups_short(const PairDesc* desc,
   }
   const UpsState st = ups[p];
   if (!st.valid) return;
-  const CpsUnit un = units[blockIdx.x];
-  const int na = un.na, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const cx<T>* Rs = rslabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
   const int64_t sp = slab_pitch(S);
-  if (tid < na) {  // the Nyquist row (signed frequency -S/2, the first row) of every column
-    const int pos = un.a0 + tid;
+  const int slab0 = blockIdx.x * NS;
+  const int slab_elems = S * 2 * kSlab;  // doubles per slab in LDS
+  if (tid < NS * kSlab && slab0 + tid / kSlab < n_slabs) {
+    // the Nyquist row (signed frequency -S/2, the first row) of every column
+    const int pos = slab_pos[slab0 + tid / kSlab] + tid % kSlab;
     const cx<T> v = Rs[(pos / kSlab) * sp + pos % kSlab];
     Nq[(int64_t)blockIdx.y * n_stored + pos2stored[pos]] = mk<double>((double)v.x, (double)v.y);
   }
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    const bool have = slab0 + ns < n_slabs;  // a missing slab is computed as zeros and not stored
+    const cx<T>* slab = Rs + (slab_pos[min(slab0 + ns, n_slabs - 1)] / kSlab) * sp;
+    double* dst = rows + ns * slab_elems;
+    constexpr int U = 8;  // loads in flight per lane: one at a time would leave the workgroup waiting on memory
+    for (int e0 = tid; e0 < S * kSlab; e0 += kThreads * U) {
+      cx<T> v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = slab[min(e0 + u * kThreads, S * kSlab - 1)];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        MS_PIN(v[u].x);
+        MS_PIN(v[u].y);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int e = e0 + u * kThreads;
+        if (e < S * kSlab) {
+          dst[2 * e] = have ? (double)v[u].x : 0.0;
+          dst[2 * e + 1] = have ? (double)v[u].y : 0.0;
+        }
+      }
+    }
+  }
+  __syncthreads();
   // results go to T1[|frequency| of the column][u]: what the second stage reads is then contiguous, and
   // the 16 displacements a lane group holds for one column are adjacent here
   double2* t1 = T1 + (int64_t)blockIdx.y * n_stored * kUpsMax;
@@ -1236,76 +1271,116 @@ __global__ __launch_bounds__(kUpsThreads) void k_ups_short(const PairDesc* desc,
   const int comp = (part != (i & 1)) ? 1 : 0;            // which component of R this lane feeds to B
   const double bsign = (part == 1 && (i & 1) == 0) ? -1.0 : 1.0;
   const int bcol = 2 * (i >> 1) + comp;
-  int pos = un.a0;
-  const int end = un.a0 + na;
-  while (pos < end) {
-    if (pos % kSlab == 0 && pos + kSlab <= end && (S & 1) == 0) {
-      __syncthreads();  // the previous slab has been consumed
-      const cx<T>* slab = Rs + (pos / kSlab) * sp;
-      for (int e = tid; e < S * kSlab; e += kUpsThreads) {
-        const cx<T> v = slab[e];
-        rows[2 * e] = (double)v.x;
-        rows[2 * e + 1] = (double)v.y;
-      }
-      __syncthreads();
-      d4 acc[kUpsTilesPerWave];
-      double2 w[kUpsTilesPerWave], step2[kUpsTilesPerWave];
+  constexpr int XN = NS >= 2 ? NS / 2 : 1;               // slabs of the shared displacement tile per wave
+  const int xs0 = NS >= 2 ? (wave >> 1) * XN : 0;
+  const bool x_on = NS >= 2 || wave < 2;                 // with one slab only two waves have a shared tile
+  const int u_tile[3] = {2 * wave, 2 * wave + 1, 8 + (wave & 1)};
+  d4 acc[2][NS], acc_x[XN];
+  double2 w[3], step2[3];
 #pragma unroll
-      for (int t = 0; t < kUpsTilesPerWave; ++t) {
-        acc[t] = d4{0.0, 0.0, 0.0, 0.0};
-        const int u = (wave * kUpsTilesPerWave + t) * 16 + i;
-        const double delta = (double)st.shift_s + ((double)u - (double)(n_up / 2)) / uf;
-        const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
-        double sn, cs;
-        sincos(theta * (double)(kk_off - S / 2), &sn, &cs);
-        w[t] = mk<double>(cs, sn);
-        sincos(2.0 * theta, &sn, &cs);
-        step2[t] = mk<double>(cs, sn);
-      }
-      for (int kk0 = 0; kk0 < S; kk0 += 2) {
-        const double bv = bsign * rows[(kk0 + kk_off) * (2 * kSlab) + bcol];
+  for (int t = 0; t < 3; ++t) {
+    const int u = u_tile[t] * 16 + i;
+    const double delta = (double)st.shift_s + ((double)u - (double)(n_up / 2)) / uf;
+    const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
+    double sn, cs;
+    sincos(theta * (double)(kk_off - S / 2), &sn, &cs);
+    w[t] = mk<double>(cs, sn);
+    sincos(2.0 * theta, &sn, &cs);
+    step2[t] = mk<double>(cs, sn);
+  }
 #pragma unroll
-        for (int t = 0; t < kUpsTilesPerWave; ++t) {  // tiles past n_up are computed too (branch-free) and not stored
-          const double av = part ? w[t].y : w[t].x;
-          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
-          w[t] = cmul(w[t], step2[t]);
-        }
-      }
-      const int c = i >> 1, o = i & 1;
-      const int kap = stored2kappa[pos2stored[pos + c]];  // 0xffff: the second stored column of a conjugate pair, unused
+  for (int ns = 0; ns < NS; ++ns) acc[0][ns] = acc[1][ns] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int t = 0; t < kUpsTilesPerWave; ++t) {
+  for (int x = 0; x < XN; ++x) acc_x[x] = d4{0.0, 0.0, 0.0, 0.0};
+  const double* brow = rows + kk_off * (2 * kSlab) + bcol;
+  for (int kk0 = 0; kk0 < S; kk0 += 2) {
+    double bv[NS];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int u = (wave * kUpsTilesPerWave + t) * 16 + k + 4 * g;
-          if (u < n_up && kap != 0xffff) {
-            double* dst = reinterpret_cast<double*>(t1 + (int64_t)kap * kUpsMax + u);
-            dst[o] = acc[t][g];
-          }
-        }
-      }
-      pos += kSlab;
-    } else {  // a unit narrower than a slab: one column at a time on the vector units
-      if (tid < n_up) {
-        const double delta = (double)st.shift_s + ((double)tid - (double)(n_up / 2)) / uf;
-        const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
-        double sn, cs;
-        sincos(theta, &sn, &cs);
-        const double2 step = mk<double>(cs, sn);
-        sincos(theta * (double)(-(S / 2)), &sn, &cs);
-        double2 ww = mk<double>(cs, sn), acc = mk<double>(0.0, 0.0);
-        const cx<T>* col = Rs + (pos / kSlab) * sp + pos % kSlab;
-        for (int kk = 0; kk < S; ++kk) {
-          const cx<T> r = col[kk * kSlab];
-          acc.x += (double)r.x * ww.x - (double)r.y * ww.y;
-          acc.y += (double)r.x * ww.y + (double)r.y * ww.x;
-          ww = cmul(ww, step);
-        }
-        const int kap = stored2kappa[pos2stored[pos]];
-        if (kap != 0xffff) t1[(int64_t)kap * kUpsMax + tid] = acc;
-      }
-      pos += 1;
+    for (int ns = 0; ns < NS; ++ns) bv[ns] = bsign * brow[ns * slab_elems + kk0 * (2 * kSlab)];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {  // tiles past n_up are computed too (branch-free) and not stored
+      const double av = part ? w[t].y : w[t].x;
+#pragma unroll
+      for (int ns = 0; ns < NS; ++ns) acc[t][ns] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[ns], acc[t][ns], 0, 0, 0);
+      w[t] = rotate(w[t], step2[t]);
     }
+    const double ax = part ? w[2].y : w[2].x;
+    if (x_on) {
+#pragma unroll
+      for (int x = 0; x < XN; ++x) {
+        double b = bv[0];
+        if constexpr (NS >= 2) {
+#pragma unroll
+          for (int ns = 1; ns < NS; ++ns) b = (xs0 + x == ns) ? bv[ns] : b;
+        }
+        acc_x[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b, acc_x[x], 0, 0, 0);
+      }
+    }
+    w[2] = rotate(w[2], step2[2]);
+  }
+  const int c = i >> 1, o = i & 1;
+  auto store = [&](int ut, int ns, const d4& v) {
+    if (slab0 + ns >= n_slabs) return;
+    const int kap = stored2kappa[pos2stored[slab_pos[slab0 + ns] + c]];  // 0xffff: the second stored column of a conjugate pair, unused
+    if (kap == 0xffff) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int u = ut * 16 + k + 4 * g;
+      if (u < n_up) reinterpret_cast<double*>(t1 + (int64_t)kap * kUpsMax + u)[o] = v[g];
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns) store(u_tile[t], ns, acc[t][ns]);
+  if (x_on) {
+#pragma unroll
+    for (int x = 0; x < XN; ++x) store(u_tile[2], xs0 + x, acc_x[x]);
+  }
+}
+
+// Stored columns that do not fill a slab: one column per workgroup on the vector units.
+// grid (n_singles, pairs_in_pass).
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_ups_short_single(const PairDesc* desc, const int8_t* status, int pair0,
+                                                               int S, int L, int want_transposed,
+                                                               const uint16_t* __restrict__ single_pos,
+                                                               const uint16_t* __restrict__ pos2stored,
+                                                               const uint16_t* __restrict__ stored2kappa, int n_stored,
+                                                               const cx<T>* __restrict__ rslabs,
+                                                               const UpsState* __restrict__ ups, int n_up, double uf,
+                                                               double2* __restrict__ T1, double2* __restrict__ Nq) {
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  {
+    const PairDesc& d = desc[p];
+    if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  }
+  const UpsState st = ups[p];
+  if (!st.valid) return;
+  const int tid = threadIdx.x;
+  const int pos = single_pos[blockIdx.x];
+  const cx<T>* col = rslabs + (int64_t)blockIdx.y * slab_pair_elems(S, L) + (pos / kSlab) * slab_pitch(S) + pos % kSlab;
+  if (tid == 0) {
+    const cx<T> v = col[0];
+    Nq[(int64_t)blockIdx.y * n_stored + pos2stored[pos]] = mk<double>((double)v.x, (double)v.y);
+  }
+  if (tid < n_up) {
+    const double delta = (double)st.shift_s + ((double)tid - (double)(n_up / 2)) / uf;
+    const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
+    double sn, cs;
+    sincos(theta, &sn, &cs);
+    const double2 step = mk<double>(cs, sn);
+    sincos(theta * (double)(-(S / 2)), &sn, &cs);
+    double2 ww = mk<double>(cs, sn), acc = mk<double>(0.0, 0.0);
+    for (int kk = 0; kk < S; ++kk) {
+      const cx<T> r = col[kk * kSlab];
+      acc.x += (double)r.x * ww.x - (double)r.y * ww.y;
+      acc.y += (double)r.x * ww.y + (double)r.y * ww.x;
+      ww = cmul(ww, step);
+    }
+    const int kap = stored2kappa[pos2stored[pos]];
+    if (kap != 0xffff) T1[((int64_t)blockIdx.y * n_stored + kap) * kUpsMax + tid] = acc;
   }
 }
 
@@ -1501,13 +1576,13 @@ __global__ __launch_bounds__(kThreads) void k_ups_long(const PairDesc* desc, con
         const double bv = part ? w[t].y : w[t].x;
 #pragma unroll
         for (int a = 0; a < kRowTiles; ++a) acc[t][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv, acc[t][a], 0, 0, 0);
-        w[t] = cmul(w[t], step2[t]);
+        w[t] = rotate(w[t], step2[t]);
       }
       const double bx = part ? w[2].y : w[2].x;
       acc_x[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(low ? av[0] : av[3], bx, acc_x[0], 0, 0, 0);
       acc_x[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(low ? av[1] : av[4], bx, acc_x[1], 0, 0, 0);
       if (low) acc_x[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bx, acc_x[2], 0, 0, 0);
-      w[2] = cmul(w[2], step2[2]);
+      w[2] = rotate(w[2], step2[2]);
     }
   }
   __syncthreads();  // sSelf is complete
@@ -2117,6 +2192,9 @@ struct ShapeCfg {
   const uint16_t* pos2stored;  // device: position -> index in stored_pos (0xffff: not stored)
   const KappaEntry* kappa;     // device: the stored column of every |frequency| 0 .. L/2 (subpixel stage)
   const uint16_t* stored2kappa;  // device: stored column -> its |frequency| (0xffff: not the column that represents it)
+  const uint16_t* ups_slabs;     // device: first position of every stored group of 8 aligned columns
+  const uint16_t* ups_singles;   // device: stored columns outside those groups
+  int n_ups_slabs, n_ups_singles;
   int NF_fwd;  // lines per k_fft_long_fwd block
   int NF_inv;  // line pairs per k_fft_long_inv block
   size_t lds_fwd, lds_cps, lds_inv;
@@ -2183,8 +2261,19 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
     const size_t kb = (kappa.size() * sizeof(KappaEntry) + 15) / 16 * 16;
     std::vector<uint16_t> s2k(stored_pos.size(), 0xffff);
     for (size_t a = 0; a < kappa.size(); ++a) s2k[kappa[a].stored] = (uint16_t)a;
+    std::vector<uint16_t> ups_slabs, ups_singles;
+    for (const CpsUnit& u : units)
+      for (int pos = u.a0; pos < u.a0 + u.na;) {
+        if (pos % kSlab == 0 && pos + kSlab <= u.a0 + u.na) {
+          ups_slabs.push_back((uint16_t)pos);
+          pos += kSlab;
+        } else {
+          ups_singles.push_back((uint16_t)pos);
+          pos += 1;
+        }
+      }
     void* blob = nullptr;
-    MS_HIP(hipMalloc(&blob, ub_pad + 2 * sb_pad + pb + kb + sb_pad));
+    MS_HIP(hipMalloc(&blob, ub_pad + 2 * sb_pad + pb + kb + 3 * sb_pad + 64));
     ctx->shape_allocs.push_back(blob);
     char* base = reinterpret_cast<char*>(blob);
     MS_HIP(hipMemcpy(base, units.data(), ub, hipMemcpyHostToDevice));
@@ -2201,6 +2290,15 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
     cfg->pos2stored = reinterpret_cast<const uint16_t*>(base + ub_pad + 2 * sb_pad);
     cfg->kappa = reinterpret_cast<const KappaEntry*>(base + ub_pad + 2 * sb_pad + pb);
     cfg->stored2kappa = reinterpret_cast<const uint16_t*>(base + ub_pad + 2 * sb_pad + pb + kb);
+    char* slabs_at = base + ub_pad + 2 * sb_pad + pb + kb + sb_pad;
+    char* singles_at = slabs_at + sb_pad + 32;
+    if (!ups_slabs.empty()) MS_HIP(hipMemcpy(slabs_at, ups_slabs.data(), ups_slabs.size() * 2, hipMemcpyHostToDevice));
+    if (!ups_singles.empty())
+      MS_HIP(hipMemcpy(singles_at, ups_singles.data(), ups_singles.size() * 2, hipMemcpyHostToDevice));
+    cfg->ups_slabs = reinterpret_cast<const uint16_t*>(slabs_at);
+    cfg->ups_singles = reinterpret_cast<const uint16_t*>(singles_at);
+    cfg->n_ups_slabs = (int)ups_slabs.size();
+    cfg->n_ups_singles = (int)ups_singles.size();
   }
   const size_t lb = f64 ? line_bytes<double>(L) : line_bytes<float>(L);
   int nf = (int)(kLdsBudget / lb);
@@ -2488,12 +2586,30 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
     MS_REQUIRE(k >= 1 && k <= 2, MISTITCH_ERR_UNSUPPORTED, "the subpixel stage needs the two-peak search");
     MS_LAUNCH(ctx, "k_ups_coarse", k_ups_coarse, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S, cfg.L,
               want_transposed, ws.partial_abs, ws.abs_stride, nblk, ws.ups);
-    const size_t lds_ups = (size_t)cfg.S * 2 * kSlab * sizeof(double);
-    if ((rc = allow_lds(ctx, k_ups_short<T>, lds_ups))) return rc;
-    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T>), dim3(cfg.n_units, n), dim3(kUpsThreads), lds_ups, ws.desc, status, pair0, cfg.S,
-              cfg.L, want_transposed, cfg.planS, cfg.units, cfg.pos2stored, cfg.stored2kappa, ws.n_stored_max, slabs, ws.ups,
-              ws.n_up, ws.uf,
-              ws.t1, ws.nq);
+    // slabs per workgroup: two, so that two workgroups per CU overlap each other's staging (four measured
+    // slower); one where LDS does not hold two
+    const size_t slab_lds = (size_t)cfg.S * 2 * kSlab * sizeof(double);
+    int ns_ups = 2;
+    if (const char* ev = getenv("MS_EXP_NS")) ns_ups = atoi(ev);
+    while (ns_ups > 1 && ns_ups * slab_lds > 144 * 1024) ns_ups >>= 1;
+    MS_REQUIRE(slab_lds <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "short side %d too long for the subpixel stage", cfg.S);
+#define MS_UPS_SHORT(NS)                                                                                              \
+  do {                                                                                                                \
+    if ((rc = allow_lds(ctx, k_ups_short<T, NS>, NS * slab_lds))) return rc;                                          \
+    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T, NS>), dim3((cfg.n_ups_slabs + NS - 1) / NS, n), dim3(kThreads),     \
+              NS * slab_lds, ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.ups_slabs, cfg.n_ups_slabs,   \
+              cfg.pos2stored, cfg.stored2kappa, ws.n_stored_max, slabs, ws.ups, ws.n_up, ws.uf, ws.t1, ws.nq);        \
+  } while (0)
+    if (cfg.n_ups_slabs > 0) {
+      if (ns_ups == 4) MS_UPS_SHORT(4);
+      else if (ns_ups == 2) MS_UPS_SHORT(2);
+      else MS_UPS_SHORT(1);
+    }
+#undef MS_UPS_SHORT
+    if (cfg.n_ups_singles > 0)
+      MS_LAUNCH(ctx, "k_ups_short_single", (k_ups_short_single<T>), dim3(cfg.n_ups_singles, n), dim3(kThreads), 0, ws.desc,
+                status, pair0, cfg.S, cfg.L, want_transposed, cfg.ups_singles, cfg.pos2stored, cfg.stored2kappa,
+                ws.n_stored_max, slabs, ws.ups, ws.n_up, ws.uf, ws.t1, ws.nq);
     MS_LAUNCH(ctx, "k_ups_nyquist", k_ups_nyquist, dim3(n), dim3(kNyqParts * 256), 0, ws.desc, status, pair0, cfg.S, cfg.L,
               want_transposed, cfg.kappa, ws.n_stored_max, ws.nq, ws.ups, ws.n_up, ws.uf, ws.gxy);
     MS_LAUNCH(ctx, "k_ups_long", k_ups_long, dim3(ws.n_row_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S, cfg.L,
