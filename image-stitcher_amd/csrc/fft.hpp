@@ -41,17 +41,30 @@ __device__ __forceinline__ C csub(C a, C b) {
 }
 template <typename C>
 __device__ __forceinline__ C cmul(C a, C b) {
+  // two products and two fused multiply-adds: the library is built with contraction off (the
+  // pixel arithmetic of the fusion kernels must round every operation), so the fusing is spelled out
+  // (complex64 keeps separate products and sums, which the compiler packs two to an instruction)
   C r;
-  r.x = a.x * b.x - a.y * b.y;
-  r.y = a.x * b.y + a.y * b.x;
+  if constexpr (sizeof(a.x) == 8) {
+    r.x = __builtin_fma(a.x, b.x, -(a.y * b.y));
+    r.y = __builtin_fma(a.x, b.y, a.y * b.x);
+  } else {
+    r.x = a.x * b.x - a.y * b.y;
+    r.y = a.x * b.y + a.y * b.x;
+  }
   return r;
 }
 // a * conj(b)
 template <typename C>
 __device__ __forceinline__ C cmulc(C a, C b) {
   C r;
-  r.x = a.x * b.x + a.y * b.y;
-  r.y = a.y * b.x - a.x * b.y;
+  if constexpr (sizeof(a.x) == 8) {
+    r.x = __builtin_fma(a.x, b.x, a.y * b.y);
+    r.y = __builtin_fma(a.y, b.x, -(a.x * b.y));
+  } else {
+    r.x = a.x * b.x + a.y * b.y;
+    r.y = a.y * b.x - a.x * b.y;
+  }
   return r;
 }
 template <typename C>
