@@ -86,6 +86,26 @@ def test_many_tiles_on_one_block_use_the_slow_path(fu):
         assert np.array_equal(got, ref), mode
 
 
+@pytest.mark.parametrize("with_ff", [False, True])
+def test_crowded_block_within_the_list(fu, with_ff):
+    """17 to 32 tiles on one output block: list indices beyond 15 reach the batched paths (two sources)
+    or must fall back to the pixel-by-pixel one (three or four sources); tile edges cut groups everywhere."""
+    rng = np.random.default_rng(11)
+    n, th, tw = 28, 40, 72
+    tiles = rng.integers(0, 65536, size=(n, th, tw), dtype=np.uint16)
+    # a loose 4 x 7 arrangement with large random offsets: between one and five tiles over most pixels
+    yx = np.array([[r * 22 + rng.integers(0, 16), c * 40 + rng.integers(0, 30)] for r in range(4) for c in range(7)],
+                  dtype=np.int32)
+    plane = np.zeros(n, dtype=np.int32)
+    mh, mw = int(yx[:, 0].max()) + th, int(yx[:, 1].max()) + tw
+    ffs = synth.make_flatfield(th, tw, amplitude=0.4)[None] if with_ff else None
+    tile_ff = np.zeros(n, dtype=np.int32) if with_ff else None
+    for mode, oracle in (("overwrite", ofu.fuse_overwrite), ("feather", ofu.fuse_feather)):
+        ref = oracle(tiles, yx, plane, 1, mh, mw, flatfields=ffs, tile_ff=tile_ff)
+        got = _np(fu.fuse_tiles(tiles, yx, plane, 1, mh, mw, flatfields=ffs, tile_ff=tile_ff, mode=mode))
+        assert np.array_equal(got, ref), mode
+
+
 def test_reference_known_answers(fu):
     names, x_mm, y_mm, zs, tiles = reference_fixture_grid(3, 3, 1000)
     infos = [fu.TileInfo(n, x, y, z, "DAPI") for n, x, y, z in zip(names, x_mm, y_mm, zs)]
