@@ -158,5 +158,6 @@ struct mistitch_ctx {
   std::map<long long, std::vector<char>> shapes;  // cached per-strip-shape launch configuration
   std::vector<void*> shape_allocs;                // device tables owned by those configurations
   std::map<int, std::vector<char>> gen_plans;     // chirp-z plans by transform length
+  std::map<long long, void*> gen_tables;          // subpixel column tables of chirp-z strip shapes (freed with shape_allocs)
   mistitch::Profiler prof;
 };

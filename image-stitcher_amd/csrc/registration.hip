@@ -1017,12 +1017,39 @@ __global__ __launch_bounds__(kThreads) void k_gen_cps(const PairDesc* desc, cons
   }
 }
 
+// Copy of the normalised spectrum for the subpixel stage, in the layout its kernels read: the columns of
+// frequency 0 .. L/2 in slabs of 8, rows in ascending signed frequency (an odd S gets an empty first row,
+// which also stands in for the Nyquist row it does not have).  grid (blocks, pairs_in_pass).
+__global__ __launch_bounds__(kThreads) void k_gen_keep_r(const PairDesc* desc, const int8_t* status, int pair0, int S,
+                                                         int L, int want_transposed, const double2* __restrict__ R,
+                                                         int Sr, int n_cols8, int64_t pair_stride,
+                                                         double2* __restrict__ out) {
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  {
+    const PairDesc& d = desc[p];
+    if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  }
+  const double2* r = R + (int64_t)blockIdx.y * S * L;
+  double2* o = out + (int64_t)blockIdx.y * pair_stride;
+  const int64_t sp = slab_pitch(Sr);
+  const int n_cols = L / 2 + 1;
+  for (int e = blockIdx.x * kThreads + threadIdx.x; e < Sr * n_cols8; e += gridDim.x * kThreads) {
+    const int kk = e / n_cols8, c = e - kk * n_cols8;
+    const int f = kk - Sr / 2;                  // signed frequency of the row
+    const int q = f < 0 ? f + S : f;            // its index in the transform
+    const bool have = c < n_cols && -f <= S / 2 && f < (S + 1) / 2;
+    o[(c / kSlab) * sp + kk * kSlab + c % kSlab] = have ? r[(int64_t)q * L + c] : mk<double>(0.0, 0.0);
+  }
+}
+
 // Inverse length-L transform of one line, scale, the line's k largest values.
 // grid (S, pairs_in_pass).
 __global__ __launch_bounds__(kThreads) void k_gen_rows_inv(const PairDesc* desc, const int8_t* status, int pair0, int S,
                                                            int L, int want_transposed, GenPlanDev gp,
                                                            const double2* __restrict__ R, int k, Peak* partial,
-                                                           int partial_stride, double* pcm_out) {
+                                                           int partial_stride, double* pcm_out, Peak* partial_abs,
+                                                           int abs_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double2* buf = reinterpret_cast<double2*>(smem_raw);
   __shared__ Peak red[kThreads / 64];
@@ -1043,6 +1070,17 @@ __global__ __launch_bounds__(kThreads) void k_gen_rows_inv(const PairDesc* desc,
     double* out = pcm_out + (int64_t)blockIdx.y * S * L;
     for (int l = tid; l < L; l += kThreads)
       out[d.transposed ? (int64_t)l * S + s : (int64_t)s * L + l] = buf[addr(0, l)].x * scale;
+  }
+  if (partial_abs != nullptr) {  // the line's largest magnitude, first in row-major order (subpixel stage)
+    Peak ba{-INFINITY, -1, -1};
+    for (int l = tid; l < L; l += kThreads) {
+      const double av = fabs(buf[addr(0, l)].x * scale);
+      const int key = d.transposed ? l * S + s : s * L + l;
+      if (first_better(av, key, ba.val, ba.key)) ba = Peak{av, key, 0};
+    }
+    const Peak best = block_argmax_first(ba, red);
+    if (tid == 0) partial_abs[(int64_t)blockIdx.y * abs_stride + blockIdx.x] = best;
+    __syncthreads();
   }
   // k rounds of block argmax; a taken element is overwritten with -inf
   for (int round = 0; round < k; ++round) {
@@ -1208,7 +1246,7 @@ static_assert(kUpsMax <= 160, "ten 16-row tiles cover the upsampled region");
 
 template <typename T, int NS>
 __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, const int8_t* status, int pair0, int S,
-                                                        int L, int want_transposed,
+                                                        int L, int want_transposed, int Sr, int64_t pair_stride,
                                                         const uint16_t* __restrict__ slab_pos, int n_slabs,
                                                         const uint16_t* __restrict__ pos2stored,
                                                         const uint16_t* __restrict__ stored2kappa, int n_stored,
@@ -1226,10 +1264,12 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
   const UpsState st = ups[p];
   if (!st.valid) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const cx<T>* Rs = rslabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
-  const int64_t sp = slab_pitch(S);
+  // Sr rows per slab, row kk holding signed frequency kk - Sr / 2 (Sr = S, or S + 1 with an empty first row
+  // when S is odd)
+  const cx<T>* Rs = rslabs + (int64_t)blockIdx.y * pair_stride;
+  const int64_t sp = slab_pitch(Sr);
   const int slab0 = blockIdx.x * NS;
-  const int slab_elems = S * 2 * kSlab;  // doubles per slab in LDS
+  const int slab_elems = Sr * 2 * kSlab;  // doubles per slab in LDS
   if (tid < NS * kSlab && slab0 + tid / kSlab < n_slabs) {
     // the Nyquist row (signed frequency -S/2, the first row) of every column
     const int pos = slab_pos[slab0 + tid / kSlab] + tid % kSlab;
@@ -1242,10 +1282,10 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
     const cx<T>* slab = Rs + (slab_pos[min(slab0 + ns, n_slabs - 1)] / kSlab) * sp;
     double* dst = rows + ns * slab_elems;
     constexpr int U = 8;  // loads in flight per lane: one at a time would leave the workgroup waiting on memory
-    for (int e0 = tid; e0 < S * kSlab; e0 += kThreads * U) {
+    for (int e0 = tid; e0 < Sr * kSlab; e0 += kThreads * U) {
       cx<T> v[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = slab[min(e0 + u * kThreads, S * kSlab - 1)];
+      for (int u = 0; u < U; ++u) v[u] = slab[min(e0 + u * kThreads, Sr * kSlab - 1)];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         MS_PIN(v[u].x);
@@ -1254,7 +1294,7 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = e0 + u * kThreads;
-        if (e < S * kSlab) {
+        if (e < Sr * kSlab) {
           dst[2 * e] = have ? (double)v[u].x : 0.0;
           dst[2 * e + 1] = have ? (double)v[u].y : 0.0;
         }
@@ -1283,7 +1323,7 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
     const double delta = (double)st.shift_s + ((double)u - (double)(n_up / 2)) / uf;
     const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
     double sn, cs;
-    sincos(theta * (double)(kk_off - S / 2), &sn, &cs);
+    sincos(theta * (double)(kk_off - Sr / 2), &sn, &cs);
     w[t] = mk<double>(cs, sn);
     sincos(2.0 * theta, &sn, &cs);
     step2[t] = mk<double>(cs, sn);
@@ -1293,7 +1333,7 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
 #pragma unroll
   for (int x = 0; x < XN; ++x) acc_x[x] = d4{0.0, 0.0, 0.0, 0.0};
   const double* brow = rows + kk_off * (2 * kSlab) + bcol;
-  for (int kk0 = 0; kk0 < S; kk0 += 2) {
+  for (int kk0 = 0; kk0 < Sr; kk0 += 2) {
     double bv[NS];
 #pragma unroll
     for (int ns = 0; ns < NS; ++ns) bv[ns] = bsign * brow[ns * slab_elems + kk0 * (2 * kSlab)];
@@ -1343,7 +1383,8 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
 // grid (n_singles, pairs_in_pass).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_ups_short_single(const PairDesc* desc, const int8_t* status, int pair0,
-                                                               int S, int L, int want_transposed,
+                                                               int S, int L, int want_transposed, int Sr,
+                                                               int64_t pair_stride,
                                                                const uint16_t* __restrict__ single_pos,
                                                                const uint16_t* __restrict__ pos2stored,
                                                                const uint16_t* __restrict__ stored2kappa, int n_stored,
@@ -1360,7 +1401,7 @@ __global__ __launch_bounds__(kThreads) void k_ups_short_single(const PairDesc* d
   if (!st.valid) return;
   const int tid = threadIdx.x;
   const int pos = single_pos[blockIdx.x];
-  const cx<T>* col = rslabs + (int64_t)blockIdx.y * slab_pair_elems(S, L) + (pos / kSlab) * slab_pitch(S) + pos % kSlab;
+  const cx<T>* col = rslabs + (int64_t)blockIdx.y * pair_stride + (pos / kSlab) * slab_pitch(Sr) + pos % kSlab;
   if (tid == 0) {
     const cx<T> v = col[0];
     Nq[(int64_t)blockIdx.y * n_stored + pos2stored[pos]] = mk<double>((double)v.x, (double)v.y);
@@ -1371,9 +1412,9 @@ __global__ __launch_bounds__(kThreads) void k_ups_short_single(const PairDesc* d
     double sn, cs;
     sincos(theta, &sn, &cs);
     const double2 step = mk<double>(cs, sn);
-    sincos(theta * (double)(-(S / 2)), &sn, &cs);
+    sincos(theta * (double)(-(Sr / 2)), &sn, &cs);
     double2 ww = mk<double>(cs, sn), acc = mk<double>(0.0, 0.0);
-    for (int kk = 0; kk < S; ++kk) {
+    for (int kk = 0; kk < Sr; ++kk) {
       const cx<T> r = col[kk * kSlab];
       acc.x += (double)r.x * ww.x - (double)r.y * ww.y;
       acc.y += (double)r.x * ww.y + (double)r.y * ww.x;
@@ -2335,6 +2376,13 @@ struct GenShape {
   GenPlanDev ps, pl;  // short axis, long axis
   int C;              // columns per k_gen_cols block
   size_t lds_rows, lds_cols;
+  // subpixel stage: the columns of frequency 0 .. L/2 are "stored" in natural order
+  int Sr;             // rows of its slabs: S, or S + 1 when S is odd
+  int n_cols8;        // L/2 + 1 rounded up to whole slabs
+  const uint16_t* ups_slabs;     // device
+  const uint16_t* ups_identity;  // device: position -> stored column, and stored column -> |frequency| (0xffff past L/2)
+  const uint16_t* ups_pos;       // device: position -> stored column (identity throughout)
+  const KappaEntry* kappa;       // device
 };
 
 // In-place radix-2 FFT in long double (host, plan construction only).
@@ -2437,6 +2485,41 @@ static int make_gen_shape(mistitch_ctx* ctx, int S, int L, GenShape* g) {
   g->lds_cols = line_s * C + tw_s;
   MS_REQUIRE(g->lds_rows <= kLdsMax && g->lds_cols <= kLdsMax, MISTITCH_ERR_UNSUPPORTED,
              "strip %d x %d needs more LDS than a workgroup has", S, L);
+  {
+    const long long key = ((long long)S << 20) | (long long)L;
+    auto it = ctx->gen_tables.find(key);
+    if (it == ctx->gen_tables.end()) {
+      const int n_cols = L / 2 + 1, n_cols8 = (n_cols + kSlab - 1) / kSlab * kSlab;
+      std::vector<uint16_t> slabs(n_cols8 / kSlab), ident(n_cols8), s2k(n_cols8, 0xffff);
+      std::vector<KappaEntry> kap(n_cols);
+      for (int i = 0; i < n_cols8 / kSlab; ++i) slabs[i] = (uint16_t)(i * kSlab);
+      for (int c = 0; c < n_cols8; ++c) ident[c] = (uint16_t)c;
+      for (int c = 0; c < n_cols; ++c) {
+        s2k[c] = (uint16_t)c;
+        kap[c] = KappaEntry{(uint16_t)c, 1, (int8_t)((c == 0 || (L % 2 == 0 && c == L / 2)) ? 1 : 0)};
+      }
+      const size_t b1 = (slabs.size() * 2 + 15) / 16 * 16, b2 = ((size_t)n_cols8 * 2 + 15) / 16 * 16;
+      const size_t b4 = kap.size() * sizeof(KappaEntry);
+      void* blob = nullptr;
+      MS_HIP(hipMalloc(&blob, b1 + 2 * b2 + b4));
+      ctx->shape_allocs.push_back(blob);
+      char* base = reinterpret_cast<char*>(blob);
+      MS_HIP(hipMemcpy(base, slabs.data(), slabs.size() * 2, hipMemcpyHostToDevice));
+      MS_HIP(hipMemcpy(base + b1, ident.data(), (size_t)n_cols8 * 2, hipMemcpyHostToDevice));
+      MS_HIP(hipMemcpy(base + b1 + b2, s2k.data(), (size_t)n_cols8 * 2, hipMemcpyHostToDevice));
+      MS_HIP(hipMemcpy(base + b1 + 2 * b2, kap.data(), b4, hipMemcpyHostToDevice));
+      it = ctx->gen_tables.emplace(key, blob).first;
+    }
+    const int n_cols = L / 2 + 1, n_cols8 = (n_cols + kSlab - 1) / kSlab * kSlab;
+    const size_t b1 = ((size_t)(n_cols8 / kSlab) * 2 + 15) / 16 * 16, b2 = ((size_t)n_cols8 * 2 + 15) / 16 * 16;
+    char* base = reinterpret_cast<char*>(it->second);
+    g->Sr = S + (S & 1);
+    g->n_cols8 = n_cols8;
+    g->ups_slabs = reinterpret_cast<const uint16_t*>(base);
+    g->ups_pos = reinterpret_cast<const uint16_t*>(base + b1);
+    g->ups_identity = reinterpret_cast<const uint16_t*>(base + b1 + b2);
+    g->kappa = reinterpret_cast<const KappaEntry*>(base + b1 + 2 * b2);
+  }
   return MISTITCH_OK;
 }
 
@@ -2447,6 +2530,7 @@ struct AnyShape {
   GenShape gen;
   int S, L;
   int nblk;           // blocks of the last pass = partial peak lists per pair
+  int n_stored;       // columns the subpixel stage works on
   size_t spec_bytes;  // per pair, in RegWorkspace::spectrum
   size_t slab_bytes;  // per pair, in RegWorkspace::slabs
 };
@@ -2463,11 +2547,13 @@ static int make_any_shape(mistitch_ctx* ctx, int S, int L, bool f64, AnyShape* a
   if (a->general) {
     if ((rc = make_gen_shape(ctx, S, L, &a->gen))) return rc;
     a->nblk = S;
+    a->n_stored = a->gen.n_cols8;
     a->spec_bytes = a->slab_bytes = (size_t)S * L * 16;
   } else {
     if ((rc = make_shape(ctx, S, L, f64, &a->fast))) return rc;
     const size_t esz = f64 ? 16 : 8;
     a->nblk = S / (2 * a->fast.NF_inv);
+    a->n_stored = a->fast.n_stored;
     a->spec_bytes = (size_t)S * (L + 128 / esz) * esz;
     a->slab_bytes = (size_t)slab_pair_elems(S, L) * esz;
   }
@@ -2553,6 +2639,58 @@ static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, size_
   return MISTITCH_OK;
 }
 
+// Column tables of the subpixel stage for one strip shape (all on the device).
+struct UpsTables {
+  const uint16_t* slabs;         // first position of every group of 8 stored columns
+  int n_slabs;
+  const uint16_t* singles;       // stored columns outside those groups
+  int n_singles;
+  const uint16_t* pos2stored;    // storage position -> stored column
+  const uint16_t* stored2kappa;  // stored column -> |frequency| (0xffff: unused)
+  const KappaEntry* kappa;       // |frequency| -> stored column, sign, self-conjugate
+};
+
+// The subpixel stage for pairs [pair0, pair0 + n) whose normalised spectra lie in `rslabs` (slabs of Sr rows
+// in ascending signed frequency, `pair_stride` elements per pair) and whose |PCM| maxima per block are in
+// ws.partial_abs (`nblk` per pair).
+template <typename T>
+static int launch_subpixel(mistitch_ctx* ctx, const UpsTables& tb, const RegWorkspace& ws, const int8_t* status, int pair0,
+                           int n, int want_transposed, int S, int L, int Sr, int64_t pair_stride, const cx<T>* rslabs,
+                           int nblk, int k) {
+  int rc;
+  MS_REQUIRE(k >= 1 && k <= 2, MISTITCH_ERR_UNSUPPORTED, "the subpixel stage needs the two-peak search");
+  MS_LAUNCH(ctx, "k_ups_coarse", k_ups_coarse, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, S, L, want_transposed,
+            ws.partial_abs, ws.abs_stride, nblk, ws.ups);
+  // slabs per workgroup: two, so that two workgroups per CU overlap each other's staging (four measured
+  // slower); one where LDS does not hold two
+  const size_t slab_lds = (size_t)Sr * 2 * kSlab * sizeof(double);
+  int ns_ups = 2;
+  while (ns_ups > 1 && ns_ups * slab_lds > 144 * 1024) ns_ups >>= 1;
+  MS_REQUIRE(slab_lds <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "short side %d too long for the subpixel stage", S);
+#define MS_UPS_SHORT(NS)                                                                                             \
+  do {                                                                                                               \
+    if ((rc = allow_lds(ctx, k_ups_short<T, NS>, NS * slab_lds))) return rc;                                         \
+    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T, NS>), dim3((tb.n_slabs + NS - 1) / NS, n), dim3(kThreads),         \
+              NS * slab_lds, ws.desc, status, pair0, S, L, want_transposed, Sr, pair_stride, tb.slabs, tb.n_slabs,   \
+              tb.pos2stored, tb.stored2kappa, ws.n_stored_max, rslabs, ws.ups, ws.n_up, ws.uf, ws.t1, ws.nq);        \
+  } while (0)
+  if (tb.n_slabs > 0) {
+    if (ns_ups == 2) MS_UPS_SHORT(2);
+    else MS_UPS_SHORT(1);
+  }
+#undef MS_UPS_SHORT
+  if (tb.n_singles > 0)
+    MS_LAUNCH(ctx, "k_ups_short_single", (k_ups_short_single<T>), dim3(tb.n_singles, n), dim3(kThreads), 0, ws.desc, status,
+              pair0, S, L, want_transposed, Sr, pair_stride, tb.singles, tb.pos2stored, tb.stored2kappa, ws.n_stored_max,
+              rslabs, ws.ups, ws.n_up, ws.uf, ws.t1, ws.nq);
+  MS_LAUNCH(ctx, "k_ups_nyquist", k_ups_nyquist, dim3(n), dim3(kNyqParts * 256), 0, ws.desc, status, pair0, S, L,
+            want_transposed, tb.kappa, ws.n_stored_max, ws.nq, ws.ups, ws.n_up, ws.uf, ws.gxy);
+  MS_LAUNCH(ctx, "k_ups_long", k_ups_long, dim3(ws.n_row_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, S, L,
+            want_transposed, tb.kappa, ws.n_stored_max, ws.t1, ws.gxy, ws.ups, ws.n_up, ws.uf, ws.partial_ups,
+            ws.n_row_blocks);
+  return MISTITCH_OK;
+}
+
 // The three FFT kernels for pairs [pair0, pair0 + n) of one canonical shape.
 template <typename T>
 static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace& ws, const int8_t* status,
@@ -2582,39 +2720,11 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
                      ws.partial_stride, pcm_out, ws.n_up ? ws.partial_abs : (Peak*)nullptr, ws.abs_stride);
   if (ws.n_up) {
     // subpixel refinement of these pairs, while their normalised spectra still sit in the slab buffer
-    const int nblk = cfg.S / (2 * cfg.NF_inv);
-    MS_REQUIRE(k >= 1 && k <= 2, MISTITCH_ERR_UNSUPPORTED, "the subpixel stage needs the two-peak search");
-    MS_LAUNCH(ctx, "k_ups_coarse", k_ups_coarse, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S, cfg.L,
-              want_transposed, ws.partial_abs, ws.abs_stride, nblk, ws.ups);
-    // slabs per workgroup: two, so that two workgroups per CU overlap each other's staging (four measured
-    // slower); one where LDS does not hold two
-    const size_t slab_lds = (size_t)cfg.S * 2 * kSlab * sizeof(double);
-    int ns_ups = 2;
-    if (const char* ev = getenv("MS_EXP_NS")) ns_ups = atoi(ev);
-    while (ns_ups > 1 && ns_ups * slab_lds > 144 * 1024) ns_ups >>= 1;
-    MS_REQUIRE(slab_lds <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "short side %d too long for the subpixel stage", cfg.S);
-#define MS_UPS_SHORT(NS)                                                                                              \
-  do {                                                                                                                \
-    if ((rc = allow_lds(ctx, k_ups_short<T, NS>, NS * slab_lds))) return rc;                                          \
-    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T, NS>), dim3((cfg.n_ups_slabs + NS - 1) / NS, n), dim3(kThreads),     \
-              NS * slab_lds, ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.ups_slabs, cfg.n_ups_slabs,   \
-              cfg.pos2stored, cfg.stored2kappa, ws.n_stored_max, slabs, ws.ups, ws.n_up, ws.uf, ws.t1, ws.nq);        \
-  } while (0)
-    if (cfg.n_ups_slabs > 0) {
-      if (ns_ups == 4) MS_UPS_SHORT(4);
-      else if (ns_ups == 2) MS_UPS_SHORT(2);
-      else MS_UPS_SHORT(1);
-    }
-#undef MS_UPS_SHORT
-    if (cfg.n_ups_singles > 0)
-      MS_LAUNCH(ctx, "k_ups_short_single", (k_ups_short_single<T>), dim3(cfg.n_ups_singles, n), dim3(kThreads), 0, ws.desc,
-                status, pair0, cfg.S, cfg.L, want_transposed, cfg.ups_singles, cfg.pos2stored, cfg.stored2kappa,
-                ws.n_stored_max, slabs, ws.ups, ws.n_up, ws.uf, ws.t1, ws.nq);
-    MS_LAUNCH(ctx, "k_ups_nyquist", k_ups_nyquist, dim3(n), dim3(kNyqParts * 256), 0, ws.desc, status, pair0, cfg.S, cfg.L,
-              want_transposed, cfg.kappa, ws.n_stored_max, ws.nq, ws.ups, ws.n_up, ws.uf, ws.gxy);
-    MS_LAUNCH(ctx, "k_ups_long", k_ups_long, dim3(ws.n_row_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, cfg.S, cfg.L,
-              want_transposed, cfg.kappa, ws.n_stored_max, ws.t1, ws.gxy, ws.ups, ws.n_up, ws.uf, ws.partial_ups,
-              ws.n_row_blocks);
+    UpsTables tabs{cfg.ups_slabs, cfg.n_ups_slabs, cfg.ups_singles, cfg.n_ups_singles, cfg.pos2stored, cfg.stored2kappa,
+                   cfg.kappa};
+    if ((rc = launch_subpixel<T>(ctx, tabs, ws, status, pair0, n, want_transposed, cfg.S, cfg.L, cfg.S,
+                                 slab_pair_elems(cfg.S, cfg.L), slabs, cfg.S / (2 * cfg.NF_inv), k)))
+      return rc;
   }
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
@@ -2638,10 +2748,26 @@ static int launch_fft_general(mistitch_ctx* ctx, const GenShape& g, const RegWor
   const int cps_blocks = std::max(1, std::min(1024, (g.S * g.L + kThreads - 1) / kThreads));
   MS_LAUNCH(ctx, "k_gen_cps", k_gen_cps, dim3(cps_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, g.S, g.L,
             want_transposed, Zf, R, eps);
+  const int64_t keep_stride = slab_pair_elems(g.Sr, g.n_cols8);
+  if (ws.n_up) {
+    // the forward spectra are no longer needed: their buffer takes the copy of R the subpixel stage reads
+    MS_REQUIRE((size_t)keep_stride <= (size_t)g.S * g.L, MISTITCH_ERR_UNSUPPORTED,
+               "strip %d x %d too small for the subpixel stage", g.S, g.L);
+    const int keep_blocks = std::max(1, std::min(256, (g.Sr * g.n_cols8 + kThreads - 1) / kThreads));
+    MS_LAUNCH(ctx, "k_gen_keep_r", k_gen_keep_r, dim3(keep_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, g.S, g.L,
+              want_transposed, R, g.Sr, g.n_cols8, keep_stride, Zf);
+  }
   MS_LAUNCH(ctx, "k_gen_cols", k_gen_cols, dim3(col_blocks, n), dim3(kThreads), g.lds_cols, ws.desc, status, pair0, g.S, g.L,
             want_transposed, g.ps, g.C, 1, R);
   MS_LAUNCH(ctx, "k_gen_rows_inv", k_gen_rows_inv, dim3(g.S, n), dim3(kThreads), g.lds_rows, ws.desc, status, pair0, g.S, g.L,
-            want_transposed, g.pl, R, k, ws.partial, ws.partial_stride, pcm_out);
+            want_transposed, g.pl, R, k, ws.partial, ws.partial_stride, pcm_out,
+            ws.n_up ? ws.partial_abs : (Peak*)nullptr, ws.abs_stride);
+  if (ws.n_up) {
+    UpsTables tabs{g.ups_slabs, g.n_cols8 / kSlab, nullptr, 0, g.ups_pos, g.ups_identity, g.kappa};
+    if ((rc = launch_subpixel<double>(ctx, tabs, ws, status, pair0, n, want_transposed, g.S, g.L, g.Sr, keep_stride, Zf,
+                                      g.S, k)))
+      return rc;
+  }
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }
@@ -2649,8 +2775,6 @@ static int launch_fft_general(mistitch_ctx* ctx, const GenShape& g, const RegWor
 static int launch_any(mistitch_ctx* ctx, const AnyShape& a, bool f64, const RegWorkspace& ws, const int8_t* status,
                       int pair0, int n, int want_transposed, bool vec_ok, int k, double* pcm_out) {
   if (a.general) {
-    MS_REQUIRE(ws.n_up == 0, MISTITCH_ERR_UNSUPPORTED,
-               "subpixel refinement needs strips with power-of-two sides (got %d x %d)", a.S, a.L);
     return launch_fft_general(ctx, a.gen, ws, status, pair0, n, want_transposed, k, pcm_out);
   }
   return f64 ? launch_fft<double>(ctx, a.fast, ws, status, pair0, n, want_transposed, vec_ok, k, pcm_out)
@@ -2721,10 +2845,8 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
   if ((rc = reserve_registration(ctx, n_pairs, chunk, (size_t)slot_elems, spec, slab, pstride, &ws))) return rc;
   const bool subpixel = (flags & MISTITCH_REG_SUBPIXEL) != 0;
   if (subpixel) {
-    MS_REQUIRE(!cfg_left.general && !cfg_top.general, MISTITCH_ERR_UNSUPPORTED,
-               "subpixel refinement needs strips with power-of-two sides");
     if ((rc = reserve_subpixel(ctx, n_pairs, chunk, std::max(cfg_left.nblk, cfg_top.nblk),
-                               std::max(cfg_left.fast.n_stored, cfg_top.fast.n_stored), ctx->upsample_factor, &ws)))
+                               std::max(cfg_left.n_stored, cfg_top.n_stored), ctx->upsample_factor, &ws)))
       return rc;
   }
   // 16-byte loads of tile rows need aligned rows; staging lines always are.
@@ -2837,9 +2959,7 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   RegWorkspace ws;
   if ((rc = reserve_registration(ctx, 1, 1, (size_t)S * L, cfg.spec_bytes, cfg.slab_bytes, pstride, &ws))) return rc;
   if (sub_out != nullptr) {
-    MS_REQUIRE(!cfg.general, MISTITCH_ERR_UNSUPPORTED, "subpixel refinement needs strips with power-of-two sides (got %d x %d)",
-               h, w);
-    if ((rc = reserve_subpixel(ctx, 1, 1, cfg.nblk, cfg.fast.n_stored, upsample, &ws))) return rc;
+    if ((rc = reserve_subpixel(ctx, 1, 1, cfg.nblk, cfg.n_stored, upsample, &ws))) return rc;
   }
   if ((rc = ctx->misc.reserve(256))) return rc;
   hipStream_t st = ctx->stream;

@@ -136,7 +136,8 @@ int mistitch_refine_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles,
  * coarse shift is the largest |PCM| value, refined on a ceil(1.5 u) square grid
  * of spacing 1/u.  Replaces skimage.registration.phase_cross_correlation(a, b,
  * upsample_factor=u, normalization='phase') as the reference calls it
- * (_translation_computation.py:1233-1272).  Power-of-two strip sides only;
+ * (_translation_computation.py:1233-1272).  Any strip sides up to 4096 (strips of
+ * other than power-of-two sides are transformed in float64 whatever the flags say);
  * 2 <= u <= 106.
  *   out_shift  [2] float64: (dy, dx)                                               */
 int mistitch_subpixel_shift(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1,

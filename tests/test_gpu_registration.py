@@ -208,6 +208,31 @@ def test_subpixel_shift_matches_upsampled_dft_oracle(reg, fft):
     assert np.abs(reg.phase_cross_correlation(a, b, 10) - osp.phase_cross_correlation(a, b, 10)).max() <= 0.1 + 1e-9
 
 
+def test_subpixel_shift_of_any_size(reg):
+    """The same for strips whose sides are not powers of two (even, odd, prime, tall): the chirp-z path."""
+    from oracle import subpixel as osp
+    for seed, (h, w, dy, dx) in enumerate([(60, 300, 0.37, -1.24), (195, 260, -2.5, 3.75), (97, 101, 0.0, 0.49),
+                                           (33, 520, 1.21, -4.68), (300, 50, -0.8, 0.15), (64, 300, 0.6, 2.2)]):
+        a, b = _subpixel_pair(60 + seed, h, w, dy, dx)
+        want = osp.phase_cross_correlation(a, b, 100)
+        got = reg.phase_cross_correlation(a, b, 100)
+        assert np.abs(got - want).max() <= 0.01 + 1e-9, (h, w, got, want)
+        assert np.abs(got - np.array([-dy, -dx])).max() < 0.1, (got, dy, dx)
+
+
+def test_register_pairs_with_subpixel_candidate_any_size(reg):
+    """Subpixel candidate on a grid whose strips are not powers of two (300 x 420 tiles, edge 45)."""
+    from oracle import subpixel as osp
+    g = synth.make_grid(33, 2, 3, 300, 420, overlap=0.15, jitter=2)
+    ref, ref_status, _ = osp.register_pairs_subpixel(g.tiles, g.pair_idx, g.pair_dir, 45)
+    out, status = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 45, subpixel=True)
+    out, status = out.cpu().numpy(), status.cpu().numpy()
+    assert np.array_equal(status != 0, ref_status != 0)
+    ok = status == 0
+    assert np.abs(out[ok, 1:] - ref[ok, 1:]).max() <= 0.01 + 1e-9
+    assert np.allclose(out[ok, 0], ref[ok, 0], rtol=0, atol=1e-12)
+
+
 def test_register_pairs_with_subpixel_candidate(reg):
     """The subpixel estimate competes as the reference's Method 2 does (listed first, wins ties)."""
     from oracle import subpixel as osp
