@@ -108,7 +108,8 @@ template <typename T>
 constexpr int kShortThreads = 512;
 
 constexpr int kSlab = 8;
-__host__ __device__ __forceinline__ int64_t slab_pitch(int S) { return (int64_t)S * kSlab + kSlab; }
+// (an odd S gets one more row: the subpixel stage wants an even count, with an empty first row then)
+__host__ __device__ __forceinline__ int64_t slab_pitch(int S) { return (int64_t)(S + (S & 1)) * kSlab + kSlab; }
 __host__ __device__ __forceinline__ int64_t slab_pair_elems(int S, int L) { return slab_pitch(S) * (L / kSlab); }
 
 __device__ __forceinline__ bool peak_better(double v, int k, double bv, int bk) {
@@ -774,8 +775,9 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       for (int u = 0; u < U; ++u) {
         const int e = min(e0 + u * kThreads, NF * n_stored - 1);  // clamp, do not branch around the loads
         const int f = NF == 1 ? 0 : e / n_stored, i = e - f * n_stored;
-        g1[u] = Z[(int64_t)(s0 + 2 * f) * Lp + i];
-        g2[u] = Z[(int64_t)(s0 + 2 * f + 1) * Lp + i];
+        // lines past the last one (odd S, or a last block that is not full) read the last line and count as zero
+        g1[u] = Z[(int64_t)min(s0 + 2 * f, S - 1) * Lp + i];
+        g2[u] = Z[(int64_t)min(s0 + 2 * f + 1, S - 1) * Lp + i];
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -788,6 +790,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
         if (e < NF * n_stored) {
           const int f = NF == 1 ? 0 : e / n_stored, i = e - f * n_stored;
           const int pos = stored_pos[i], mir = mirror_fill[i];
+          if (s0 + 2 * f >= S) g1[u] = mk<T>((T)0, (T)0);
+          if (s0 + 2 * f + 1 >= S) g2[u] = mk<T>((T)0, (T)0);
           buf[addr(f, pos)] = mk<T>(g1[u].x - g2[u].y, g1[u].y + g2[u].x);  // g1 + i g2
           if (mir != 0xffff) buf[addr(f, mir)] = mk<T>(g1[u].x + g2[u].y, g2[u].x - g1[u].y);  // conj(g1) + i conj(g2)
         }
@@ -806,11 +810,11 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       const cx<T> v = buf[addr(f, l)];
       const int s = s0 + 2 * f;
       if (d.transposed) {
-        out[(int64_t)l * S + s] = (double)v.x * scale;
-        out[(int64_t)l * S + s + 1] = (double)v.y * scale;
+        if (s < S) out[(int64_t)l * S + s] = (double)v.x * scale;
+        if (s + 1 < S) out[(int64_t)l * S + s + 1] = (double)v.y * scale;
       } else {
-        out[(int64_t)s * L + l] = (double)v.x * scale;
-        out[(int64_t)(s + 1) * L + l] = (double)v.y * scale;
+        if (s < S) out[(int64_t)s * L + l] = (double)v.x * scale;
+        if (s + 1 < S) out[(int64_t)(s + 1) * L + l] = (double)v.y * scale;
       }
     }
   }
@@ -820,8 +824,11 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   if (k <= 2) {
     // The production case: one scan keeps each lane's two best values, then k argmax
     // rounds in which a lane whose best was taken offers its second best.
-    // Values are compared unscaled (the scale is a power of two on this path, so nothing
-    // changes order or creates ties) and carried as (value, key) only.
+    // Values are compared unscaled where the scale is a power of two (nothing then changes order or
+    // creates ties), scaled otherwise, and carried as (value, key) only.
+    const bool exact_scale = (S & (S - 1)) == 0;
+    const T cmp_scale = exact_scale ? (T)1 : (T)scale;
+    const double out_scale = exact_scale ? scale : 1.0;
     T v1 = neg_inf, v2 = neg_inf;
     int k1 = -1, k2 = -1;
     Peak ba{-INFINITY, -1, -1};  // largest magnitude, first in row-major order (subpixel stage only)
@@ -839,15 +846,16 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       const int s = s0 + 2 * f;
       const int key0 = d.transposed ? l * S + s : s * L + l;
       const int key1 = d.transposed ? key0 + 1 : key0 + L;
-      offer(v.x, key0);
-      offer(v.y, key1);
+      const bool have0 = s < S, have1 = s + 1 < S;  // an odd S leaves the last transform half empty
+      if (have0) offer(v.x * cmp_scale, key0);
+      if (have1) offer(v.y * cmp_scale, key1);
       if (partial_abs != nullptr) {
         const double a0v = fabs((double)v.x * scale), a1v = fabs((double)v.y * scale);
-        if (first_better(a0v, key0, ba.val, ba.key)) ba = Peak{a0v, key0, 0};
-        if (first_better(a1v, key1, ba.val, ba.key)) ba = Peak{a1v, key1, 0};
+        if (have0 && first_better(a0v, key0, ba.val, ba.key)) ba = Peak{a0v, key0, 0};
+        if (have1 && first_better(a1v, key1, ba.val, ba.key)) ba = Peak{a1v, key1, 0};
       }
     }
-    Peak b1{k1 >= 0 ? (double)v1 * scale : -INFINITY, k1, k1}, b2{k2 >= 0 ? (double)v2 * scale : -INFINITY, k2, k2};
+    Peak b1{k1 >= 0 ? (double)v1 * out_scale : -INFINITY, k1, k1}, b2{k2 >= 0 ? (double)v2 * out_scale : -INFINITY, k2, k2};
     if (partial_abs != nullptr) {
       const Peak best = block_argmax_first(ba, red);
       if (tid == 0) partial_abs[(int64_t)blockIdx.y * abs_stride + blockIdx.x] = best;
@@ -875,8 +883,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       const int key0 = d.transposed ? l * S + s : s * L + l;
       const int key1 = d.transposed ? key0 + 1 : key0 + L;
       const double v0 = (double)v.x * scale, v1 = (double)v.y * scale;
-      if (v.x != neg_inf && peak_better(v0, key0, mine.val, mine.key)) mine = Peak{v0, key0, 2 * a0};
-      if (v.y != neg_inf && peak_better(v1, key1, mine.val, mine.key)) mine = Peak{v1, key1, 2 * a0 + 1};
+      if (s < S && v.x != neg_inf && peak_better(v0, key0, mine.val, mine.key)) mine = Peak{v0, key0, 2 * a0};
+      if (s + 1 < S && v.y != neg_inf && peak_better(v1, key1, mine.val, mine.key)) mine = Peak{v1, key1, 2 * a0 + 1};
     }
     Peak best = block_argmax(mine, red);
     if (tid == 0) {
@@ -937,6 +945,86 @@ __device__ __forceinline__ void bluestein_lines(double2* buf, const LineAddr<dou
     buf[a] = cmul(buf[a], c);
   }
   __syncthreads();
+}
+
+// The column pass for a short side that is not a power of two (the long side is one: the row passes stay
+// as they are): the same unit structure, the length-S transforms done by chirp-z in LDS (complex128 only),
+// columns as contiguous lines.  Rows come out in natural frequency order.
+// grid (n_units, pairs_in_pass).
+__global__ __launch_bounds__(kThreads) void k_fft_short_cps_gen(const PairDesc* desc, const int8_t* status, int pair0,
+                                                                int S, int L, int want_transposed, GenPlanDev gpS,
+                                                                FftPlanDev planL, const CpsUnit* __restrict__ units,
+                                                                int lines, const double2* slabs, double2* spectrum,
+                                                                double eps, double2* keep_r,
+                                                                const uint16_t* __restrict__ pos2stored, int n_stored) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double2* buf = reinterpret_cast<double2*>(smem_raw);
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  {
+    const PairDesc& d = desc[p];
+    if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  }
+  const CpsUnit un = units[blockIdx.x];
+  const int na = un.na, ncol = un.na + un.nb;
+  const int tid = threadIdx.x;
+  const int Lp = spectrum_pitch<double>(n_stored);
+  double2* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
+  const int64_t sp = slab_pitch(S);
+  const double2* Zs = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
+  const LineAddr<double> addr{LineAddr<double>::padded(gpS.M) + 1};
+  const Twiddles<double> tw = load_twiddles<double>(buf + lines * addr.fstride, gpS.planM, tid, kThreads);
+  const int lncol = 31 - __builtin_clz(ncol), lna = 31 - __builtin_clz(na);
+  const int mp = planL.mpos[un.a0 + (tid & (na - 1))];  // column c of a lane's cells is the same on every trip
+  const int col0 = pos2stored[un.a0];
+  for (int e = tid; e < S * ncol; e += kThreads) {
+    const int q = e >> lncol, c = e & (ncol - 1);
+    const int pos = c < na ? un.a0 + c : un.b0 + (c - na);
+    buf[addr(c, q)] = Zs[(pos / kSlab) * sp + q * kSlab + pos % kSlab];
+  }
+  __syncthreads();
+  bluestein_lines(buf, addr, ncol, gpS, tw, false, tid, kThreads);
+  const bool partner_in_a = mp >= un.a0 && mp < un.a0 + na;
+  const int pc = partner_in_a ? (mp - un.a0) : (na + mp - un.b0);
+  for (int e = tid; e < S * na; e += kThreads) {
+    const int q = e >> lna, c = e & (na - 1);
+    const int q2 = q == 0 ? 0 : S - q;
+    if (partner_in_a && (q2 * 64 + pc) < (q * 64 + c)) continue;  // the partner cell's owner writes both
+    const double2 z = buf[addr(c, q)];
+    const double2 zm = buf[addr(pc, q2)];
+    const double ax = 0.5 * (z.x + zm.x), ay = 0.5 * (z.y - zm.y);
+    const double bx = 0.5 * (z.y + zm.y), by = -0.5 * (z.x - zm.x);
+    double fx = ax * bx + ay * by;  // A * conj(B)
+    double fy = ay * bx - ax * by;
+    const double inv = 1.0 / (cabs_safe<double>(fx, fy) + eps);
+    fx *= inv;
+    fy *= inv;
+    buf[addr(c, q)] = mk<double>(fx, fy);
+    if (partner_in_a && (q2 * 64 + pc) != (q * 64 + c)) buf[addr(pc, q2)] = mk<double>(fx, -fy);
+  }
+  __syncthreads();
+  if (keep_r != nullptr) {
+    // the subpixel stage's copy: rows in ascending signed frequency from row Sr / 2 - S / 2 on; an odd S
+    // leaves the first of its Sr = S + 1 rows empty
+    double2* Rs = keep_r + (int64_t)blockIdx.y * slab_pair_elems(S, L);
+    const int Sr = S + (S & 1);
+    for (int e = tid; e < S * na; e += kThreads) {
+      const int q = e >> lna, c = e & (na - 1);
+      const int pos = un.a0 + c;
+      const int f = q < (S + 1) / 2 ? q : q - S;
+      Rs[(pos / kSlab) * sp + (f + Sr / 2) * kSlab + pos % kSlab] = buf[addr(c, q)];
+    }
+    if ((S & 1) && tid < na) {
+      const int pos = un.a0 + tid;
+      Rs[(pos / kSlab) * sp + pos % kSlab] = mk<double>(0.0, 0.0);
+    }
+    __syncthreads();
+  }
+  bluestein_lines(buf, addr, na, gpS, tw, true, tid, kThreads);
+  for (int e = tid; e < S * na; e += kThreads) {
+    const int q = e >> lna, c = e & (na - 1);
+    Z[(int64_t)q * Lp + col0 + c] = buf[addr(c, q)];
+  }
 }
 
 // z = a + i b per line, length-L transform, natural order out.  grid (S, pairs_in_pass).
@@ -1274,7 +1362,8 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
     // the Nyquist row (signed frequency -S/2, the first row) of every column
     const int pos = slab_pos[slab0 + tid / kSlab] + tid % kSlab;
     const cx<T> v = Rs[(pos / kSlab) * sp + pos % kSlab];
-    Nq[(int64_t)blockIdx.y * n_stored + pos2stored[pos]] = mk<double>((double)v.x, (double)v.y);
+    const int col = pos2stored[pos];  // 0xffff: a column of the group that is not stored
+    if (col != 0xffff) Nq[(int64_t)blockIdx.y * n_stored + col] = mk<double>((double)v.x, (double)v.y);
   }
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) {
@@ -1361,8 +1450,10 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
   const int c = i >> 1, o = i & 1;
   auto store = [&](int ut, int ns, const d4& v) {
     if (slab0 + ns >= n_slabs) return;
-    const int kap = stored2kappa[pos2stored[slab_pos[slab0 + ns] + c]];  // 0xffff: the second stored column of a conjugate pair, unused
-    if (kap == 0xffff) return;
+    const int col = pos2stored[slab_pos[slab0 + ns] + c];
+    if (col == 0xffff) return;  // not a stored column
+    const int kap = stored2kappa[col];
+    if (kap == 0xffff) return;  // the second stored column of a conjugate pair: unused
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int u = ut * 16 + k + 4 * g;
@@ -1376,52 +1467,6 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
   if (x_on) {
 #pragma unroll
     for (int x = 0; x < XN; ++x) store(u_tile[2], xs0 + x, acc_x[x]);
-  }
-}
-
-// Stored columns that do not fill a slab: one column per workgroup on the vector units.
-// grid (n_singles, pairs_in_pass).
-template <typename T>
-__global__ __launch_bounds__(kThreads) void k_ups_short_single(const PairDesc* desc, const int8_t* status, int pair0,
-                                                               int S, int L, int want_transposed, int Sr,
-                                                               int64_t pair_stride,
-                                                               const uint16_t* __restrict__ single_pos,
-                                                               const uint16_t* __restrict__ pos2stored,
-                                                               const uint16_t* __restrict__ stored2kappa, int n_stored,
-                                                               const cx<T>* __restrict__ rslabs,
-                                                               const UpsState* __restrict__ ups, int n_up, double uf,
-                                                               double2* __restrict__ T1, double2* __restrict__ Nq) {
-  const int p = pair0 + blockIdx.y;
-  if (status[p] != MISTITCH_PAIR_OK) return;
-  {
-    const PairDesc& d = desc[p];
-    if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
-  }
-  const UpsState st = ups[p];
-  if (!st.valid) return;
-  const int tid = threadIdx.x;
-  const int pos = single_pos[blockIdx.x];
-  const cx<T>* col = rslabs + (int64_t)blockIdx.y * pair_stride + (pos / kSlab) * slab_pitch(Sr) + pos % kSlab;
-  if (tid == 0) {
-    const cx<T> v = col[0];
-    Nq[(int64_t)blockIdx.y * n_stored + pos2stored[pos]] = mk<double>((double)v.x, (double)v.y);
-  }
-  if (tid < n_up) {
-    const double delta = (double)st.shift_s + ((double)tid - (double)(n_up / 2)) / uf;
-    const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
-    double sn, cs;
-    sincos(theta, &sn, &cs);
-    const double2 step = mk<double>(cs, sn);
-    sincos(theta * (double)(-(Sr / 2)), &sn, &cs);
-    double2 ww = mk<double>(cs, sn), acc = mk<double>(0.0, 0.0);
-    for (int kk = 0; kk < Sr; ++kk) {
-      const cx<T> r = col[kk * kSlab];
-      acc.x += (double)r.x * ww.x - (double)r.y * ww.y;
-      acc.y += (double)r.x * ww.y + (double)r.y * ww.x;
-      ww = cmul(ww, step);
-    }
-    const int kap = stored2kappa[pos2stored[pos]];
-    if (kap != 0xffff) T1[((int64_t)blockIdx.y * n_stored + kap) * kUpsMax + tid] = acc;
   }
 }
 
@@ -2223,6 +2268,8 @@ static bool build_units(const std::vector<uint16_t>& mpos, int L, int C, std::ve
 
 struct ShapeCfg {
   int S, L;
+  bool gen_short;   // the short side is not a power of two: its transforms run by chirp-z (complex128 only)
+  GenPlanDev gpS;   // the chirp-z plan of the short axis then (planS unused)
   FftPlanDev planS, planL;
   int C;       // columns per block of the column pass (LDS rows hold 2C)
   const CpsUnit* units;    // device
@@ -2233,9 +2280,8 @@ struct ShapeCfg {
   const uint16_t* pos2stored;  // device: position -> index in stored_pos (0xffff: not stored)
   const KappaEntry* kappa;     // device: the stored column of every |frequency| 0 .. L/2 (subpixel stage)
   const uint16_t* stored2kappa;  // device: stored column -> its |frequency| (0xffff: not the column that represents it)
-  const uint16_t* ups_slabs;     // device: first position of every stored group of 8 aligned columns
-  const uint16_t* ups_singles;   // device: stored columns outside those groups
-  int n_ups_slabs, n_ups_singles;
+  const uint16_t* ups_slabs;     // device: first position of every aligned group of 8 positions with a stored column
+  int n_ups_slabs;
   int NF_fwd;  // lines per k_fft_long_fwd block
   int NF_inv;  // line pairs per k_fft_long_inv block
   size_t lds_fwd, lds_cps, lds_inv;
@@ -2249,9 +2295,13 @@ static size_t line_bytes(int L) {
   return (size_t)(LineAddr<T>::padded(L) + 1) * sizeof(cx<T>);
 }
 
+static int build_gen_plan(mistitch_ctx* ctx, int n, GenPlanDev* out);
+
 static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) {
-  MS_REQUIRE(is_pow2(S) && is_pow2(L) && S >= 8 && L >= 8 && L <= 4096 && S <= 1024, MISTITCH_ERR_UNSUPPORTED,
-             "strip %d x %d unsupported: sides must be powers of two, long side in [8, 4096], short side in [8, 1024]",
+  const bool gen_short = !is_pow2(S);
+  MS_REQUIRE(is_pow2(L) && L >= 8 && L <= 4096 && S <= 1024 && (gen_short ? (S >= 3 && f64) : S >= 8),
+             MISTITCH_ERR_UNSUPPORTED,
+             "strip %d x %d unsupported here: the long side must be a power of two in [8, 4096], the short side at most 1024",
              S, L);
   const long long key = (((long long)S << 20) | (long long)L) * 2 + (f64 ? 1 : 0);
   auto it = ctx->shapes.find(key);
@@ -2261,7 +2311,15 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   }
   cfg->S = S;
   cfg->L = L;
-  int rc = build_plan(ctx, S, f64, &cfg->planS, f64 ? kShortMaxRadix<double> : kShortMaxRadix<float>);
+  cfg->gen_short = gen_short;
+  int rc;
+  if (gen_short) {
+    rc = build_gen_plan(ctx, S, &cfg->gpS);
+    memset(&cfg->planS, 0, sizeof(cfg->planS));
+  } else {
+    rc = build_plan(ctx, S, f64, &cfg->planS, f64 ? kShortMaxRadix<double> : kShortMaxRadix<float>);
+    memset(&cfg->gpS, 0, sizeof(cfg->gpS));
+  }
   if (rc) return rc;
   rc = build_plan(ctx, L, f64, &cfg->planL, f64 ? kLongMaxRadix<double> : kLongMaxRadix<float>);
   if (rc) return rc;
@@ -2271,16 +2329,22 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   // widest column block whose units exist and whose working set leaves room for two blocks per CU
   std::vector<CpsUnit> units;
   std::vector<uint16_t> stored_pos, mirror_fill;
-  int C = 16;
+  // (chirp-z columns are lines of M >= 2S - 1 elements: 76 KiB still leaves room for two blocks per CU)
+  const size_t col_bytes = gen_short ? line_bytes<double>(cfg->gpS.M) : (size_t)S * esz;
+  const size_t col_budget = gen_short ? 76 * 1024 : kLdsBudget;
+  int C = gen_short ? 8 : 16;
   for (; C >= 1; C >>= 1) {
     if (C > L) continue;
-    if (C > 1 && (size_t)S * 2 * C * esz > kLdsBudget) continue;
+    if (C > 1 && col_bytes * 2 * C > col_budget) continue;
     if (build_units(mpos, L, C, &units, &stored_pos, &mirror_fill)) break;
   }
   MS_REQUIRE(C >= 1, MISTITCH_ERR_UNSUPPORTED, "no column-pass decomposition for long side %d", L);
   cfg->C = C;
-  cfg->lds_cps = ((size_t)S * 2 * C + (f64 ? Twiddles<double>::entries(S) : Twiddles<float>::entries(S))) * esz +
-                 ((size_t)S * 4 + 15) / 16 * 16;  // + two uint16 index tables of the short axis
+  if (gen_short)
+    cfg->lds_cps = col_bytes * 2 * C + (size_t)Twiddles<double>::entries(cfg->gpS.M) * 16;
+  else
+    cfg->lds_cps = ((size_t)S * 2 * C + (f64 ? Twiddles<double>::entries(S) : Twiddles<float>::entries(S))) * esz +
+                   ((size_t)S * 4 + 15) / 16 * 16;  // + two uint16 index tables of the short axis
   MS_REQUIRE(cfg->lds_cps <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "short side %d needs %zu B of LDS", S, cfg->lds_cps);
   {
     std::vector<uint16_t> pos2freq(L), pos2stored(L, 0xffff);
@@ -2302,17 +2366,15 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
     const size_t kb = (kappa.size() * sizeof(KappaEntry) + 15) / 16 * 16;
     std::vector<uint16_t> s2k(stored_pos.size(), 0xffff);
     for (size_t a = 0; a < kappa.size(); ++a) s2k[kappa[a].stored] = (uint16_t)a;
-    std::vector<uint16_t> ups_slabs, ups_singles;
-    for (const CpsUnit& u : units)
-      for (int pos = u.a0; pos < u.a0 + u.na;) {
-        if (pos % kSlab == 0 && pos + kSlab <= u.a0 + u.na) {
-          ups_slabs.push_back((uint16_t)pos);
-          pos += kSlab;
-        } else {
-          ups_singles.push_back((uint16_t)pos);
-          pos += 1;
-        }
-      }
+    // the subpixel stage walks every aligned group of 8 positions that holds a stored column (columns of a
+    // group that are not stored are computed along and dropped)
+    std::vector<uint16_t> ups_slabs;
+    {
+      std::vector<char> has(L / kSlab, 0);
+      for (uint16_t pos : stored_pos) has[pos / kSlab] = 1;
+      for (int i = 0; i < L / kSlab; ++i)
+        if (has[i]) ups_slabs.push_back((uint16_t)(i * kSlab));
+    }
     void* blob = nullptr;
     MS_HIP(hipMalloc(&blob, ub_pad + 2 * sb_pad + pb + kb + 3 * sb_pad + 64));
     ctx->shape_allocs.push_back(blob);
@@ -2332,14 +2394,9 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
     cfg->kappa = reinterpret_cast<const KappaEntry*>(base + ub_pad + 2 * sb_pad + pb);
     cfg->stored2kappa = reinterpret_cast<const uint16_t*>(base + ub_pad + 2 * sb_pad + pb + kb);
     char* slabs_at = base + ub_pad + 2 * sb_pad + pb + kb + sb_pad;
-    char* singles_at = slabs_at + sb_pad + 32;
     if (!ups_slabs.empty()) MS_HIP(hipMemcpy(slabs_at, ups_slabs.data(), ups_slabs.size() * 2, hipMemcpyHostToDevice));
-    if (!ups_singles.empty())
-      MS_HIP(hipMemcpy(singles_at, ups_singles.data(), ups_singles.size() * 2, hipMemcpyHostToDevice));
     cfg->ups_slabs = reinterpret_cast<const uint16_t*>(slabs_at);
-    cfg->ups_singles = reinterpret_cast<const uint16_t*>(singles_at);
     cfg->n_ups_slabs = (int)ups_slabs.size();
-    cfg->n_ups_singles = (int)ups_singles.size();
   }
   const size_t lb = f64 ? line_bytes<double>(L) : line_bytes<float>(L);
   int nf = (int)(kLdsBudget / lb);
@@ -2348,8 +2405,10 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   if (want < 1) want = 1;
   if (nf > want) nf = want;
   while (nf & (nf - 1)) nf &= nf - 1;  // round down to a power of two
-  cfg->NF_fwd = nf > S ? S : nf;
-  cfg->NF_inv = nf > S / 2 ? S / 2 : nf;
+  cfg->NF_fwd = nf;  // a power of two that divides S: whole blocks of lines
+  while (cfg->NF_fwd > S || S % cfg->NF_fwd) cfg->NF_fwd >>= 1;
+  cfg->NF_inv = nf > (S + 1) / 2 ? (S + 1) / 2 : nf;
+  while (cfg->NF_inv & (cfg->NF_inv - 1)) cfg->NF_inv &= cfg->NF_inv - 1;
   const size_t twb = (size_t)(f64 ? Twiddles<double>::entries(L) : Twiddles<float>::entries(L)) * esz;
   cfg->lds_fwd = lb * cfg->NF_fwd + twb;
   cfg->lds_inv = lb * cfg->NF_inv + twb;
@@ -2531,12 +2590,16 @@ struct AnyShape {
   int S, L;
   int nblk;           // blocks of the last pass = partial peak lists per pair
   int n_stored;       // columns the subpixel stage works on
+  bool f64;           // precision of the Hermitian path for this shape
   size_t spec_bytes;  // per pair, in RegWorkspace::spectrum
   size_t slab_bytes;  // per pair, in RegWorkspace::slabs
 };
 
+// Power-of-two sides take the Hermitian path; so does a strip whose LONG side alone is a power of two (the
+// usual case of 2048-pixel tiles with an arbitrary edge width), with chirp-z transforms on the short axis
+// only and in complex128 whatever precision was asked for.
 static bool fast_shape_ok(int S, int L) {
-  return is_pow2(S) && is_pow2(L) && S >= 8 && L >= 8 && L <= 4096 && S <= 1024;
+  return is_pow2(L) && L >= 8 && L <= 4096 && S <= 1024 && (is_pow2(S) ? S >= 8 : S >= 3);
 }
 
 static int make_any_shape(mistitch_ctx* ctx, int S, int L, bool f64, AnyShape* a) {
@@ -2550,9 +2613,10 @@ static int make_any_shape(mistitch_ctx* ctx, int S, int L, bool f64, AnyShape* a
     a->n_stored = a->gen.n_cols8;
     a->spec_bytes = a->slab_bytes = (size_t)S * L * 16;
   } else {
-    if ((rc = make_shape(ctx, S, L, f64, &a->fast))) return rc;
-    const size_t esz = f64 ? 16 : 8;
-    a->nblk = S / (2 * a->fast.NF_inv);
+    a->f64 = f64 || !is_pow2(S);
+    if ((rc = make_shape(ctx, S, L, a->f64, &a->fast))) return rc;
+    const size_t esz = a->f64 ? 16 : 8;
+    a->nblk = (S + 2 * a->fast.NF_inv - 1) / (2 * a->fast.NF_inv);
     a->n_stored = a->fast.n_stored;
     a->spec_bytes = (size_t)S * (L + 128 / esz) * esz;
     a->slab_bytes = (size_t)slab_pair_elems(S, L) * esz;
@@ -2641,10 +2705,8 @@ static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, size_
 
 // Column tables of the subpixel stage for one strip shape (all on the device).
 struct UpsTables {
-  const uint16_t* slabs;         // first position of every group of 8 stored columns
+  const uint16_t* slabs;         // first position of every aligned group of 8 positions with a stored column
   int n_slabs;
-  const uint16_t* singles;       // stored columns outside those groups
-  int n_singles;
   const uint16_t* pos2stored;    // storage position -> stored column
   const uint16_t* stored2kappa;  // stored column -> |frequency| (0xffff: unused)
   const KappaEntry* kappa;       // |frequency| -> stored column, sign, self-conjugate
@@ -2679,10 +2741,6 @@ static int launch_subpixel(mistitch_ctx* ctx, const UpsTables& tb, const RegWork
     else MS_UPS_SHORT(1);
   }
 #undef MS_UPS_SHORT
-  if (tb.n_singles > 0)
-    MS_LAUNCH(ctx, "k_ups_short_single", (k_ups_short_single<T>), dim3(tb.n_singles, n), dim3(kThreads), 0, ws.desc, status,
-              pair0, S, L, want_transposed, Sr, pair_stride, tb.singles, tb.pos2stored, tb.stored2kappa, ws.n_stored_max,
-              rslabs, ws.ups, ws.n_up, ws.uf, ws.t1, ws.nq);
   MS_LAUNCH(ctx, "k_ups_nyquist", k_ups_nyquist, dim3(n), dim3(kNyqParts * 256), 0, ws.desc, status, pair0, S, L,
             want_transposed, tb.kappa, ws.n_stored_max, ws.nq, ws.ups, ws.n_up, ws.uf, ws.gxy);
   MS_LAUNCH(ctx, "k_ups_long", k_ups_long, dim3(ws.n_row_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, S, L,
@@ -2707,23 +2765,35 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
     MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd<T, false>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd,
                        ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, slabs);
   }
-  constexpr int kNT = kShortThreads<T>, kSR = kShortMaxRadix<T>;
-  if ((rc = allow_lds(ctx, k_fft_short_cps<T, kNT, kSR>, cfg.lds_cps))) return rc;
   const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
-  MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<T, kNT, kSR>), dim3(cfg.n_units, n), dim3(kNT), cfg.lds_cps, ws.desc, status,
-            pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps,
-            ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
+  bool column_pass_done = false;
+  if constexpr (std::is_same<T, double>::value) {
+    if (cfg.gen_short) {
+      if ((rc = allow_lds(ctx, k_fft_short_cps_gen, cfg.lds_cps))) return rc;
+      MS_LAUNCH(ctx, "k_fft_short_cps", k_fft_short_cps_gen, dim3(cfg.n_units, n), dim3(kThreads), cfg.lds_cps, ws.desc, status,
+                pair0, cfg.S, cfg.L, want_transposed, cfg.gpS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps,
+                ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
+      column_pass_done = true;
+    }
+  }
+  if (!column_pass_done) {
+    MS_REQUIRE(!cfg.gen_short, MISTITCH_ERR_UNSUPPORTED, "a short side of %d needs the complex128 path", cfg.S);
+    constexpr int kNT = kShortThreads<T>, kSR = kShortMaxRadix<T>;
+    if ((rc = allow_lds(ctx, k_fft_short_cps<T, kNT, kSR>, cfg.lds_cps))) return rc;
+    MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<T, kNT, kSR>), dim3(cfg.n_units, n), dim3(kNT), cfg.lds_cps, ws.desc,
+              status, pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps,
+              ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
+  }
   if ((rc = allow_lds(ctx, k_fft_long_inv<T>, cfg.lds_inv))) return rc;
-  MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv<T>), dim3(cfg.S / (2 * cfg.NF_inv), n), dim3(kThreads), cfg.lds_inv, ws.desc,
+  MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv<T>), dim3((cfg.S + 2 * cfg.NF_inv - 1) / (2 * cfg.NF_inv), n), dim3(kThreads), cfg.lds_inv, ws.desc,
                      status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored,
             cfg.NF_inv, spec, k, ws.partial,
                      ws.partial_stride, pcm_out, ws.n_up ? ws.partial_abs : (Peak*)nullptr, ws.abs_stride);
   if (ws.n_up) {
     // subpixel refinement of these pairs, while their normalised spectra still sit in the slab buffer
-    UpsTables tabs{cfg.ups_slabs, cfg.n_ups_slabs, cfg.ups_singles, cfg.n_ups_singles, cfg.pos2stored, cfg.stored2kappa,
-                   cfg.kappa};
-    if ((rc = launch_subpixel<T>(ctx, tabs, ws, status, pair0, n, want_transposed, cfg.S, cfg.L, cfg.S,
-                                 slab_pair_elems(cfg.S, cfg.L), slabs, cfg.S / (2 * cfg.NF_inv), k)))
+    UpsTables tabs{cfg.ups_slabs, cfg.n_ups_slabs, cfg.pos2stored, cfg.stored2kappa, cfg.kappa};
+    if ((rc = launch_subpixel<T>(ctx, tabs, ws, status, pair0, n, want_transposed, cfg.S, cfg.L, cfg.S + (cfg.S & 1),
+                                 slab_pair_elems(cfg.S, cfg.L), slabs, (cfg.S + 2 * cfg.NF_inv - 1) / (2 * cfg.NF_inv), k)))
       return rc;
   }
   MS_HIP(hipGetLastError());
@@ -2763,7 +2833,7 @@ static int launch_fft_general(mistitch_ctx* ctx, const GenShape& g, const RegWor
             want_transposed, g.pl, R, k, ws.partial, ws.partial_stride, pcm_out,
             ws.n_up ? ws.partial_abs : (Peak*)nullptr, ws.abs_stride);
   if (ws.n_up) {
-    UpsTables tabs{g.ups_slabs, g.n_cols8 / kSlab, nullptr, 0, g.ups_pos, g.ups_identity, g.kappa};
+    UpsTables tabs{g.ups_slabs, g.n_cols8 / kSlab, g.ups_pos, g.ups_identity, g.kappa};
     if ((rc = launch_subpixel<double>(ctx, tabs, ws, status, pair0, n, want_transposed, g.S, g.L, g.Sr, keep_stride, Zf,
                                       g.S, k)))
       return rc;
@@ -2777,8 +2847,8 @@ static int launch_any(mistitch_ctx* ctx, const AnyShape& a, bool f64, const RegW
   if (a.general) {
     return launch_fft_general(ctx, a.gen, ws, status, pair0, n, want_transposed, k, pcm_out);
   }
-  return f64 ? launch_fft<double>(ctx, a.fast, ws, status, pair0, n, want_transposed, vec_ok, k, pcm_out)
-             : launch_fft<float>(ctx, a.fast, ws, status, pair0, n, want_transposed, vec_ok, k, pcm_out);
+  return a.f64 ? launch_fft<double>(ctx, a.fast, ws, status, pair0, n, want_transposed, vec_ok, k, pcm_out)
+               : launch_fft<float>(ctx, a.fast, ws, status, pair0, n, want_transposed, vec_ok, k, pcm_out);
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

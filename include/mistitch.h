@@ -96,8 +96,10 @@ int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int
  * worse, and y, x are then fractional.
  *
  * Strips whose sides are powers of two (long side 8..4096, short side 8..1024)
- * take the Hermitian radix-16 path; any other side lengths up to 4096 take
- * chirp-z transforms (complex128 whatever `flags` says, several times slower).
+ * take the Hermitian radix-16 path; with a power-of-two long side and any short
+ * side up to 1024 only the column transforms become chirp-z ones (complex128
+ * whatever `flags` says, about 2.5 times slower); any other side lengths up to
+ * 4096 take chirp-z transforms on both axes (complex128, several times slower).
  */
 int mistitch_register_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h,
                             int tile_w, int64_t tile_pitch, const int32_t* pair_idx,

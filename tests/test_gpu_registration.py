@@ -44,7 +44,8 @@ def test_unsupported_shape_is_an_error(reg):
         reg.register_pairs(tiles, [[0, 1]], [1], 16)
 
 
-@pytest.mark.parametrize("shape", [(50, 300), (195, 512), (97, 101), (64, 300), (30, 1000), (7, 9), (130, 64)])
+@pytest.mark.parametrize("shape", [(50, 300), (195, 512), (97, 101), (64, 300), (30, 1000), (7, 9), (130, 64),
+                                   (100, 256), (45, 1024), (2048, 195), (3, 64), (9, 8)])
 def test_pcm_of_any_size(reg, shape):
     """PCM and its ranking for strips whose sides are not powers of two (primes, odd, tall)."""
     h, w = shape
@@ -212,7 +213,8 @@ def test_subpixel_shift_of_any_size(reg):
     """The same for strips whose sides are not powers of two (even, odd, prime, tall): the chirp-z path."""
     from oracle import subpixel as osp
     for seed, (h, w, dy, dx) in enumerate([(60, 300, 0.37, -1.24), (195, 260, -2.5, 3.75), (97, 101, 0.0, 0.49),
-                                           (33, 520, 1.21, -4.68), (300, 50, -0.8, 0.15), (64, 300, 0.6, 2.2)]):
+                                           (33, 520, 1.21, -4.68), (300, 50, -0.8, 0.15), (64, 300, 0.6, 2.2),
+                                           (60, 256, 0.3, 1.7), (45, 512, -1.4, 0.85), (512, 75, 2.6, -0.35)]):
         a, b = _subpixel_pair(60 + seed, h, w, dy, dx)
         want = osp.phase_cross_correlation(a, b, 100)
         got = reg.phase_cross_correlation(a, b, 100)
