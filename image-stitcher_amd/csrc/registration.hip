@@ -417,8 +417,10 @@ __device__ __forceinline__ unsigned ff_corrected(unsigned v, const void* ff, int
 // the staging buffer in canonical [S][L] layout (left strips transposed), corrected as
 // load_batch_images corrects whole tiles before the reference cuts its edges
 // (tile_registration.py:2184-2279).  Only a quarter of the pixels of a tile lie in strips.
-// Sides multiples of 64, 16-byte aligned rows.  grid (max L / 64, max S / 64, 2 * pairs_in_pass).
-template <int FF>
+// Long sides multiples of 64, 16-byte aligned rows.  EDGE: the short side (the edge width) is arbitrary;
+// the left strips then start at an unaligned column and are read pixel by pixel.
+// grid (max L / 64, ceil(max S / 64), 2 * pairs_in_pass).
+template <int FF, bool EDGE>
 __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, int64_t tile_pitch, int H, int W,
                                                         int w_left, int w_top, const int32_t* pair_idx,
                                                         const PairDesc* desc, const int8_t* status, int pair0,
@@ -435,21 +437,32 @@ __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, i
   if (d.transposed) {
     // image rows l0 .. l0+63, image columns x0 + s0 .. +63
     const int x0 = (which == 0 ? W - w_left : 0) + s0;
+    if constexpr (EDGE) {
+      const int c = t & 63;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int y = l0 + row + 32 * i;
-      const int64_t at = (int64_t)y * W + x0 + 8 * sub;
-      const uint4 v = *reinterpret_cast<const uint4*>(img + at);
-      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
-      unsigned* dstw = reinterpret_cast<unsigned*>(&tile[row + 32 * i][8 * sub]);  // rows are 132 bytes: 4-byte aligned
+      for (int i = 0; i < 16; ++i) {
+        const int r = (t >> 6) + 4 * i;
+        const int64_t at = (int64_t)(l0 + r) * W + x0 + c;
+        tile[r][c] = s0 + c < d.S ? (uint16_t)ff_corrected<FF>(img[at], ff, at) : (uint16_t)0;
+      }
+    } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        dstw[q] = ff_corrected<FF>(w4[q] & 0xffffu, ff, at + 2 * q) | (ff_corrected<FF>(w4[q] >> 16, ff, at + 2 * q + 1) << 16);
+      for (int i = 0; i < 2; ++i) {
+        const int y = l0 + row + 32 * i;
+        const int64_t at = (int64_t)y * W + x0 + 8 * sub;
+        const uint4 v = *reinterpret_cast<const uint4*>(img + at);
+        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+        unsigned* dstw = reinterpret_cast<unsigned*>(&tile[row + 32 * i][8 * sub]);  // rows are 132 bytes: 4-byte aligned
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          dstw[q] = ff_corrected<FF>(w4[q] & 0xffffu, ff, at + 2 * q) | (ff_corrected<FF>(w4[q] >> 16, ff, at + 2 * q + 1) << 16);
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int sline = row + 32 * i;  // output line
+      if (EDGE && s0 + sline >= d.S) continue;
       uint4 o;
       unsigned w4[4];
 #pragma unroll
@@ -466,6 +479,7 @@ __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, i
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int sline = row + 32 * i;
+      if (EDGE && s0 + sline >= d.S) continue;
       const int64_t at = (int64_t)(y0 + sline) * W + l0 + 8 * sub;
       const uint4 v = *reinterpret_cast<const uint4*>(img + at);
       const unsigned w4[4] = {v.x, v.y, v.z, v.w};
@@ -2934,15 +2948,21 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
     bool vec_strips = vec_top;  // may the top strips be read with 16-byte loads
     if (ff != nullptr) {
       // corrected strips of both directions go to the staging buffer; the featureless test reads them there
-      const bool fast = vec_top && H % 64 == 0 && W % 64 == 0 && w_left % 64 == 0 && w_top % 64 == 0;
-      if (fast) {
-        const dim3 grid(std::max(H, W) / 64, std::max(w_left, w_top) / 64, 2 * n);
-        if (ff_type == MISTITCH_FF_F32)
-          MS_LAUNCH(ctx, "k_stage_strips", k_stage_strips64<MISTITCH_FF_F32>, grid, dim3(256), 0, tiles, tile_pitch, H, W, w_left,
-                    w_top, pair_idx, ws.desc, status, pair0, ff);
-        else
-          MS_LAUNCH(ctx, "k_stage_strips", k_stage_strips64<MISTITCH_FF_F64>, grid, dim3(256), 0, tiles, tile_pitch, H, W, w_left,
-                    w_top, pair_idx, ws.desc, status, pair0, ff);
+      const bool tiled = vec_top && H % 64 == 0 && W % 64 == 0;
+      const bool fast = tiled && w_left % 64 == 0 && w_top % 64 == 0;
+      if (tiled) {
+        const dim3 grid(std::max(H, W) / 64, (std::max(w_left, w_top) + 63) / 64, 2 * n);
+#define MS_STAGE(FF, EDGE)                                                                                           \
+  MS_LAUNCH(ctx, "k_stage_strips", (k_stage_strips64<FF, EDGE>), grid, dim3(256), 0, tiles, tile_pitch, H, W, w_left, \
+            w_top, pair_idx, ws.desc, status, pair0, ff)
+        if (ff_type == MISTITCH_FF_F32) {
+          if (fast) MS_STAGE(MISTITCH_FF_F32, false);
+          else MS_STAGE(MISTITCH_FF_F32, true);
+        } else {
+          if (fast) MS_STAGE(MISTITCH_FF_F64, false);
+          else MS_STAGE(MISTITCH_FF_F64, true);
+        }
+#undef MS_STAGE
       } else {
         const dim3 grid(256, 2 * n);
         if (ff_type == MISTITCH_FF_F32)

@@ -296,7 +296,8 @@ def test_select_best_registration_channel(reg):
 
 
 @pytest.mark.parametrize("shape,edge,dt", [((256, 256), 64, np.float32), ((128, 320), 64, np.float64),
-                                           ((200, 300), 50, np.float32)])
+                                           ((200, 300), 50, np.float32), ((256, 320), 45, np.float32),
+                                           ((192, 256), 100, np.float64)])
 def test_register_pairs_with_fused_flatfield(reg, shape, edge, dt):
     """Strips corrected on the way == whole tiles corrected first (oracle), featureless test included."""
     from oracle import fusion as ofu
