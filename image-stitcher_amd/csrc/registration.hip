@@ -961,11 +961,74 @@ __device__ __forceinline__ void bluestein_lines(double2* buf, const LineAddr<dou
   __syncthreads();
 }
 
+// The same with the chirp and filter values a lane needs held in registers (lane tid of an NT-wide
+// workgroup only ever touches elements tid + NT j of a line) and no division in the element loops:
+// for n <= kThreads * kBlueC and M <= kThreads * kBlueH.
+constexpr int kGenShortThreads = 512, kGenShortRadix = 8;  // as the power-of-two column pass: more waves, radix-8 plans
+constexpr int kBlueC = 2, kBlueH = 4;
+struct BluesteinRegs {
+  double2 c[kBlueC];  // chirp[tid + NT j]
+  double2 h[kBlueH];  // bhat[tid + NT j]
+};
+template <int NT>
+__device__ __forceinline__ BluesteinRegs bluestein_load(const GenPlanDev& gp, int tid) {
+  BluesteinRegs r;
+#pragma unroll
+  for (int j = 0; j < kBlueC; ++j) r.c[j] = gp.chirp[min(tid + NT * j, gp.n - 1)];
+#pragma unroll
+  for (int j = 0; j < kBlueH; ++j) r.h[j] = gp.bhat[min(tid + NT * j, gp.M - 1)];
+  return r;
+}
+template <int NT, int MAXR>
+__device__ __forceinline__ void bluestein_lines_r(double2* buf, const LineAddr<double>& addr, int nl, const GenPlanDev& gp,
+                                                  const BluesteinRegs& r, const Twiddles<double>& tw, bool inverse, int tid) {
+  const int n = gp.n, M = gp.M;
+  const double sgn = inverse ? -1.0 : 1.0;
+  for (int f = 0; f < nl; ++f) {
+#pragma unroll
+    for (int j = 0; j < kBlueH; ++j) {
+      const int i = tid + NT * j;
+      if (i < M) {
+        const int a = addr(f, i);
+        if (j < kBlueC && i < n)
+          buf[a] = cmul(buf[a], mk<double>(r.c[j < kBlueC ? j : 0].x, sgn * r.c[j < kBlueC ? j : 0].y));
+        else
+          buf[a] = mk<double>(0.0, 0.0);
+      }
+    }
+  }
+  __syncthreads();
+  fft_forward<double, MAXR>(buf, addr, nl, gp.planM, tw, tid, NT);
+  for (int f = 0; f < nl; ++f) {
+#pragma unroll
+    for (int j = 0; j < kBlueH; ++j) {
+      const int pos = tid + NT * j;
+      if (pos < M) {
+        const int a = addr(f, pos);
+        buf[a] = cmul(buf[a], mk<double>(r.h[j].x, sgn * r.h[j].y));
+      }
+    }
+  }
+  __syncthreads();
+  fft_inverse<double, MAXR>(buf, addr, nl, gp.planM, tw, tid, NT);
+  for (int f = 0; f < nl; ++f) {
+#pragma unroll
+    for (int j = 0; j < kBlueC; ++j) {
+      const int i = tid + NT * j;
+      if (i < n) {
+        const int a = addr(f, i);
+        buf[a] = cmul(buf[a], mk<double>(r.c[j].x, sgn * r.c[j].y));
+      }
+    }
+  }
+  __syncthreads();
+}
+
 // The column pass for a short side that is not a power of two (the long side is one: the row passes stay
 // as they are): the same unit structure, the length-S transforms done by chirp-z in LDS (complex128 only),
 // columns as contiguous lines.  Rows come out in natural frequency order.
 // grid (n_units, pairs_in_pass).
-__global__ __launch_bounds__(kThreads) void k_fft_short_cps_gen(const PairDesc* desc, const int8_t* status, int pair0,
+__global__ __launch_bounds__(kGenShortThreads) void k_fft_short_cps_gen(const PairDesc* desc, const int8_t* status, int pair0,
                                                                 int S, int L, int want_transposed, GenPlanDev gpS,
                                                                 FftPlanDev planL, const CpsUnit* __restrict__ units,
                                                                 int lines, const double2* slabs, double2* spectrum,
@@ -987,20 +1050,21 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps_gen(const PairDesc* 
   const int64_t sp = slab_pitch(S);
   const double2* Zs = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
   const LineAddr<double> addr{LineAddr<double>::padded(gpS.M) + 1};
-  const Twiddles<double> tw = load_twiddles<double>(buf + lines * addr.fstride, gpS.planM, tid, kThreads);
+  const Twiddles<double> tw = load_twiddles<double>(buf + lines * addr.fstride, gpS.planM, tid, kGenShortThreads);
   const int lncol = 31 - __builtin_clz(ncol), lna = 31 - __builtin_clz(na);
   const int mp = planL.mpos[un.a0 + (tid & (na - 1))];  // column c of a lane's cells is the same on every trip
   const int col0 = pos2stored[un.a0];
-  for (int e = tid; e < S * ncol; e += kThreads) {
+  const BluesteinRegs br = bluestein_load<kGenShortThreads>(gpS, tid);
+  for (int e = tid; e < S * ncol; e += kGenShortThreads) {
     const int q = e >> lncol, c = e & (ncol - 1);
     const int pos = c < na ? un.a0 + c : un.b0 + (c - na);
     buf[addr(c, q)] = Zs[(pos / kSlab) * sp + q * kSlab + pos % kSlab];
   }
   __syncthreads();
-  bluestein_lines(buf, addr, ncol, gpS, tw, false, tid, kThreads);
+  bluestein_lines_r<kGenShortThreads, kGenShortRadix>(buf, addr, ncol, gpS, br, tw, false, tid);
   const bool partner_in_a = mp >= un.a0 && mp < un.a0 + na;
   const int pc = partner_in_a ? (mp - un.a0) : (na + mp - un.b0);
-  for (int e = tid; e < S * na; e += kThreads) {
+  for (int e = tid; e < S * na; e += kGenShortThreads) {
     const int q = e >> lna, c = e & (na - 1);
     const int q2 = q == 0 ? 0 : S - q;
     if (partner_in_a && (q2 * 64 + pc) < (q * 64 + c)) continue;  // the partner cell's owner writes both
@@ -1022,7 +1086,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps_gen(const PairDesc* 
     // leaves the first of its Sr = S + 1 rows empty
     double2* Rs = keep_r + (int64_t)blockIdx.y * slab_pair_elems(S, L);
     const int Sr = S + (S & 1);
-    for (int e = tid; e < S * na; e += kThreads) {
+    for (int e = tid; e < S * na; e += kGenShortThreads) {
       const int q = e >> lna, c = e & (na - 1);
       const int pos = un.a0 + c;
       const int f = q < (S + 1) / 2 ? q : q - S;
@@ -1034,8 +1098,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_short_cps_gen(const PairDesc* 
     }
     __syncthreads();
   }
-  bluestein_lines(buf, addr, na, gpS, tw, true, tid, kThreads);
-  for (int e = tid; e < S * na; e += kThreads) {
+  bluestein_lines_r<kGenShortThreads, kGenShortRadix>(buf, addr, na, gpS, br, tw, true, tid);
+  for (int e = tid; e < S * na; e += kGenShortThreads) {
     const int q = e >> lna, c = e & (na - 1);
     Z[(int64_t)q * Lp + col0 + c] = buf[addr(c, q)];
   }
@@ -2309,7 +2373,7 @@ static size_t line_bytes(int L) {
   return (size_t)(LineAddr<T>::padded(L) + 1) * sizeof(cx<T>);
 }
 
-static int build_gen_plan(mistitch_ctx* ctx, int n, GenPlanDev* out);
+static int build_gen_plan(mistitch_ctx* ctx, int n, GenPlanDev* out, int max_radix = 16);
 
 static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) {
   const bool gen_short = !is_pow2(S);
@@ -2328,7 +2392,7 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   cfg->gen_short = gen_short;
   int rc;
   if (gen_short) {
-    rc = build_gen_plan(ctx, S, &cfg->gpS);
+    rc = build_gen_plan(ctx, S, &cfg->gpS, kGenShortRadix);
     memset(&cfg->planS, 0, sizeof(cfg->planS));
   } else {
     rc = build_plan(ctx, S, f64, &cfg->planS, f64 ? kShortMaxRadix<double> : kShortMaxRadix<float>);
@@ -2487,8 +2551,9 @@ static void host_fft(std::vector<long double>& re, std::vector<long double>& im)
   }
 }
 
-static int build_gen_plan(mistitch_ctx* ctx, int n, GenPlanDev* out) {
-  auto it = ctx->gen_plans.find(n);
+static int build_gen_plan(mistitch_ctx* ctx, int n, GenPlanDev* out, int max_radix) {
+  const int plan_key = n * 32 + max_radix;
+  auto it = ctx->gen_plans.find(plan_key);
   if (it != ctx->gen_plans.end()) {
     memcpy(out, it->second.data(), sizeof(GenPlanDev));
     return MISTITCH_OK;
@@ -2499,7 +2564,7 @@ static int build_gen_plan(mistitch_ctx* ctx, int n, GenPlanDev* out) {
   GenPlanDev gp;
   gp.n = n;
   gp.M = M;
-  int rc = build_plan(ctx, M, true, &gp.planM);
+  int rc = build_plan(ctx, M, true, &gp.planM, max_radix);
   if (rc) return rc;
   const long double pi = 3.14159265358979323846264338327950288L;
   std::vector<double> chirp(2 * (size_t)n);
@@ -2535,7 +2600,7 @@ static int build_gen_plan(mistitch_ctx* ctx, int n, GenPlanDev* out) {
   gp.bhat = reinterpret_cast<const double2*>(reinterpret_cast<char*>(blob) + cb);
   std::vector<char> rec(sizeof(GenPlanDev));
   memcpy(rec.data(), &gp, sizeof(GenPlanDev));
-  ctx->gen_plans[n] = rec;
+  ctx->gen_plans[plan_key] = rec;
   *out = gp;
   return MISTITCH_OK;
 }
@@ -2784,7 +2849,7 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
   if constexpr (std::is_same<T, double>::value) {
     if (cfg.gen_short) {
       if ((rc = allow_lds(ctx, k_fft_short_cps_gen, cfg.lds_cps))) return rc;
-      MS_LAUNCH(ctx, "k_fft_short_cps", k_fft_short_cps_gen, dim3(cfg.n_units, n), dim3(kThreads), cfg.lds_cps, ws.desc, status,
+      MS_LAUNCH(ctx, "k_fft_short_cps", k_fft_short_cps_gen, dim3(cfg.n_units, n), dim3(kGenShortThreads), cfg.lds_cps, ws.desc, status,
                 pair0, cfg.S, cfg.L, want_transposed, cfg.gpS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps,
                 ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
       column_pass_done = true;
