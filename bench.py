@@ -286,6 +286,18 @@ def main():
         step_registration_subpixel()
         t_reg_sub = timed(step_registration_subpixel, args.steps)
         out3_np = d_out2.cpu().numpy()
+        # host-to-device rate of a pinned buffer of tile data (what an ingest stage would pay; never part of `value`)
+        n_h2d = min(64, tiles.shape[1])
+        pinned = torch.empty((n_h2d, tile, tile), dtype=torch.int16).pin_memory()
+        dst_h2d = torch.empty_like(pinned, device=device)
+        dst_h2d.copy_(pinned, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dst_h2d.copy_(pinned, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_gbs = 3 * pinned.numel() * 2 / (time.perf_counter() - t0) / 1e9
+        del pinned, dst_h2d
 
     # ---- parity properties at full size: every planted shift recovered, mosaic spot checks ----
     out_np, st_np = d_out.cpu().numpy(), d_status.cpu().numpy()
@@ -411,6 +423,8 @@ def main():
                 "ms_per_step": round(1e3 * t_reg_other / args.steps, 3),
                 "planted_integer_shifts_recovered": shifts_ok_other}
         if side:
+            line["host_to_device"] = {"GB/s": round(h2d_gbs, 1), "sample": f"{n_h2d} tiles from pinned host memory, 3 copies",
+                                      "upload_of_this_workload_s": round(tiles.numel() * 2 / h2d_gbs / 1e9, 3)}
             line["registration_subpixel"] = {
                 "value": round(world * n_pairs * args.steps / t_reg_sub, 1), "unit": "tile-pairs/s",
                 "ms_per_step": round(1e3 * t_reg_sub / args.steps, 3), "upsample_factor": 100,
