@@ -56,6 +56,8 @@ def test_pcm_of_any_size(reg, shape):
     got = reg.pcm(a, b)
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() < 1e-11
+    # such strips are transformed in complex128 whatever precision is asked for
+    assert np.array_equal(reg.pcm(a, b, fft="f32"), got)
     k = 4
     rows, cols, vals = reg.pcm_topk(a, b, k)
     er, ec, ev = oreg.multi_peak_max(ref)
