@@ -652,12 +652,13 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
   const int p = pair0 + blockIdx.y;
-  if (status[p] != MISTITCH_PAIR_OK) return;
-  {
-    const PairDesc& d = desc[p];
-    if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
-  }
+  // every lookup that does not depend on another goes out before the first test: one memory round trip
+  // instead of three in front of the column loads
+  const int8_t pair_status = status[p];
+  const int d_S = desc[p].S, d_L = desc[p].L, d_transposed = desc[p].transposed;
   const CpsUnit un = units[blockIdx.x];
+  if (pair_status != MISTITCH_PAIR_OK) return;
+  if (d_S != S || d_L != L || (want_transposed >= 0 && d_transposed != want_transposed)) return;
   const int na = un.na, ncol = un.na + un.nb;
   const int tid = threadIdx.x;
   const int Lp = spectrum_pitch<T>(n_stored);
@@ -768,9 +769,10 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
   __shared__ Peak red[kThreads / 64];
   const int p = pair0 + blockIdx.y;
-  if (status[p] != MISTITCH_PAIR_OK) return;
+  // the pair's status and descriptor are looked up here but tested only once the spectrum loads are on their
+  // way (the workspace rows exist whatever the pair's state): one memory round trip in front of the transform
+  const int8_t pair_status = status[p];
   const PairDesc d = desc[p];
-  if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
   const int tid = threadIdx.x;
   LineAddr<T> addr{LineAddr<T>::padded(L) + 1};
   const Twiddles<T> tw = load_twiddles<T>(buf + NF * addr.fstride, planL, tid, kThreads);
@@ -793,6 +795,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
         g1[u] = Z[(int64_t)min(s0 + 2 * f, S - 1) * Lp + i];
         g2[u] = Z[(int64_t)min(s0 + 2 * f + 1, S - 1) * Lp + i];
       }
+      if (pair_status != MISTITCH_PAIR_OK || d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed))
+        return;  // the same for every lane of the workgroup
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         MS_PIN(g1[u].x); MS_PIN(g1[u].y);
