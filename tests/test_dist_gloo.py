@@ -1,7 +1,8 @@
 """The N>1 partitioning and the pair-result all-gather, on CPU with gloo (world_size 2).
 
 The per-rank compute is stood in for by the oracle: what is under test is the
-sharding, the halo bookkeeping and the collective, not the kernels."""
+sharding, the halo bookkeeping, the collective and the replicated position solve
+between registration and fusion, not the kernels."""
 import os
 import socket
 
@@ -12,7 +13,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from image_stitcher_amd import dist as mdist
-from image_stitcher_amd import synth
+from image_stitcher_amd import solve, synth
 from oracle import fusion as ofu
 from oracle import registration as oreg
 
@@ -39,8 +40,13 @@ def _worker(rank, world, port, q):
         rows, status = mdist.all_gather_pair_results(torch.from_numpy(out), torch.from_numpy(st), counts)
         lists = [mdist.shard_pairs_by_grid_rows(g.pair_idx, g.cols, g.rows, world, r)[0] for r in range(world)]
         g_rows, g_st = mdist.scatter_to_global(lists, rows, status, len(g.pair_idx))
+        # every rank holds every pair now and solves the (tiny) position problem for itself
+        row, col = np.repeat(np.arange(g.rows), g.cols), np.tile(np.arange(g.cols), g.rows)
+        res = solve.solve_positions(solve.grid_from_pairs(row, col, g.pair_idx, g.pair_dir, g_rows.numpy(),
+                                                          g_st.numpy()), 128, 128)
+        yx = np.stack([res.y_pos, res.x_pos], axis=1).astype(np.int32)
+        assert np.array_equal(yx, g.true_yx - g.true_yx.min(axis=0))
         # fusion bands
-        yx = (g.true_yx - g.true_yx.min(axis=0)).astype(np.int32)
         mh, mw = int(yx[:, 0].max()) + 128, int(yx[:, 1].max()) + 128
         r0, r1 = mdist.shard_mosaic_rows(mh, world, rank, align=64)
         use = mdist.tiles_touching_rows(yx[:, 0], 128, r0, r1)
