@@ -81,3 +81,32 @@ def test_grid_with_a_featureless_tile_is_placed_from_the_stage(reg):
     ref = solve.solve_positions(solve.grid_from_pairs(row, col, g.pair_idx, g.pair_dir, cpu, cpu_status,
                                                       stage_x, stage_y), 256, 256)
     assert np.array_equal(ref.y_pos, res.y_pos) and np.array_equal(ref.x_pos, res.x_pos)
+
+
+@pytest.mark.parametrize("mode", ["overwrite", "feather"])
+def test_register_solve_fuse_reassembles_the_scene(reg, mode):
+    """The whole path on one grid: tiles cut from a scene at jittered positions, pairs registered
+    on the device, positions solved, tiles fused at those positions.  Every covered mosaic pixel
+    must be the scene pixel it was cut from (overlapping tiles agree there, so the blend of equal
+    values is that value)."""
+    from image_stitcher_amd import fusion
+    rows, cols, t, jitter, overlap = 4, 5, 512, 4, 0.10
+    seed = 91
+    g = synth.make_grid(seed, rows, cols, t, t, overlap=overlap, jitter=jitter)
+    scene = synth.make_scene(seed, (rows - 1) * g.pitch_y + t + 2 * jitter, (cols - 1) * g.pitch_x + t + 2 * jitter)
+    out, status = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 64)
+    row, col = np.repeat(np.arange(rows), cols), np.tile(np.arange(cols), rows)
+    res = solve.solve_positions(solve.grid_from_pairs(row, col, g.pair_idx, g.pair_dir, out.cpu().numpy(),
+                                                      status.cpu().numpy()), t, t)
+    yx = np.stack([res.y_pos, res.x_pos], axis=1).astype(np.int32)
+    mh, mw = int(yx[:, 0].max()) + t, int(yx[:, 1].max()) + t
+    mosaic = fusion.fuse_tiles(g.tiles, yx, np.zeros(rows * cols, dtype=np.int32), 1, mh, mw, mode=mode)
+    mosaic = mosaic.cpu().numpy()[0]
+    y0, x0 = g.true_yx.min(axis=0)
+    covered = np.zeros((mh, mw), dtype=bool)
+    for y, x in yx:
+        covered[y:y + t, x:x + t] = True
+    want = scene[y0:y0 + mh, x0:x0 + mw]
+    assert covered.mean() > 0.99
+    assert np.array_equal(mosaic[covered], want[covered])
+    assert (mosaic[~covered] == 0).all()
