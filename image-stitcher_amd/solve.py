@@ -163,6 +163,16 @@ def _above(v: np.ndarray, thr: float) -> np.ndarray:
         return v > thr
 
 
+def _median(v: np.ndarray) -> float:
+    """Median of a short vector without NaN: middle element, or the mean of the two middle ones
+    (what ``np.median`` and the pandas median return, minus their dispatch cost)."""
+    a = np.sort(v, axis=None)
+    n = a.shape[0]
+    if n == 0:
+        return float("nan")
+    return float(a[n // 2]) if n & 1 else float((a[n // 2 - 1] + a[n // 2]) / 2)
+
+
 def image_overlap(first: np.ndarray, rows: np.ndarray, size_y: int, size_x: int) -> Tuple[float, float]:
     """Median (y / size_y, x / size_x) over the selected pairs (_stage_model.py:87-163)."""
     t = np.stack([first[rows, Y] / size_y, first[rows, X] / size_x])
@@ -271,7 +281,7 @@ def filter_translations(grid: TranslationGrid, cfg: FilterConfig) -> FilterResul
             ok = g & valid2[d]
             if not ok.any():
                 continue
-            medy, medx = np.nanmedian(f[ok, Y]), np.nanmedian(f[ok, X])
+            medy, medx = _median(f[ok, Y]), _median(f[ok, X])
             v3[g] = (_between(f[g, Y], medy - r, medy + r) & _between(f[g, X], medx - r, medx + r)
                      & _above(f[g, NCC], cfg.ncc_threshold))
         valid3[d] = v3
@@ -287,15 +297,15 @@ def filter_translations(grid: TranslationGrid, cfg: FilterConfig) -> FilterResul
             if not ok.any():
                 continue
             bad = g & ~valid3[d]
-            s[bad, Y] = np.nanmedian(f[ok, Y])
-            s[bad, X] = np.nanmedian(f[ok, X])
+            s[bad, Y] = _median(f[ok, Y])
+            s[bad, X] = _median(f[ok, X])
             s[bad, NCC] = 0.0
             est |= bad
         for axis in (X, Y):
             hole = np.isnan(s[:, axis])
             if hole.any():
                 rest = s[~hole, axis]
-                s[hole, axis] = np.median(rest) if rest.shape[0] else np.nan
+                s[hole, axis] = _median(rest)
                 s[hole, NCC] = 0.0
                 est |= hole
         second[d], estimated[d] = s, est
@@ -312,19 +322,19 @@ def filter_translations(grid: TranslationGrid, cfg: FilterConfig) -> FilterResul
 def candidate_edges(grid: TranslationGrid, valid3: Dict[str, np.ndarray]) -> List[TreeEdge]:
     """Every measured pair that may enter the tree, in the reference's insertion order: tile by
     tile, left before top (_global_optimization.py:139-211, weights :318-371)."""
+    ok = {}
+    for d in DIRECTIONS:
+        f = grid.first[d]
+        with np.errstate(invalid="ignore"):
+            ok[d] = ((grid.neighbour[d] >= 0) & (f[:, NCC] >= MIN_VALID_WEIGHT) & (f[:, NCC] <= MAX_VALID_WEIGHT)
+                     & (np.abs(f[:, Y]) <= MAX_TRANSLATION_PX) & (np.abs(f[:, X]) <= MAX_TRANSLATION_PX))
     edges = []
-    for i in range(grid.n_tiles):
+    for i in np.nonzero(ok["left"] | ok["top"])[0].tolist():
         for d in DIRECTIONS:
-            nb = int(grid.neighbour[d][i])
-            if nb < 0:
-                continue
-            ncc, y, x = (float(v) for v in grid.first[d][i])
-            if np.isnan(ncc) or not (MIN_VALID_WEIGHT <= ncc <= MAX_VALID_WEIGHT):
-                continue
-            if not (np.isfinite(y) and np.isfinite(x)) or abs(y) > MAX_TRANSLATION_PX or abs(x) > MAX_TRANSLATION_PX:
-                continue
-            weight = ncc + (VALID_TRANSLATION_WEIGHT_BONUS if bool(valid3[d][i]) else 0.0)
-            edges.append(TreeEdge(i, nb, d, weight, y, x))
+            if ok[d][i]:
+                ncc, y, x = grid.first[d][i].tolist()
+                weight = ncc + (VALID_TRANSLATION_WEIGHT_BONUS if valid3[d][i] else 0.0)
+                edges.append(TreeEdge(i, int(grid.neighbour[d][i]), d, weight, y, x))
     return edges
 
 
