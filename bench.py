@@ -304,6 +304,14 @@ def main():
     expected = true_yx[pair_idx[:, 1]] - true_yx[pair_idx[:, 0]]
     shifts_ok = bool((st_np == 0).all() and np.array_equal(out_np[:, 1:].astype(np.int64), expected))
 
+    # ---- the host step between the two device stages: pair rows -> tile positions (never part of `value`) ----
+    from image_stitcher_amd import solve
+    grid_row, grid_col = np.repeat(np.arange(cfg["rows"]), cfg["cols"]), np.tile(np.arange(cfg["cols"]), cfg["rows"])
+    t0 = time.perf_counter()
+    solved = solve.solve_positions(solve.grid_from_pairs(grid_row, grid_col, pair_idx, pair_dir, out_np, st_np), tile, tile)
+    t_solve = time.perf_counter() - t0
+    positions_ok = bool(np.array_equal(np.stack([solved.y_pos, solved.x_pos], axis=1), yx_np))
+
     # ---- per-kernel durations from HIP events on the launch stream ----
     kernels = {}
     if not args.no_profile:
@@ -405,7 +413,10 @@ def main():
                                     "unit": "GB/s", "frac": round(fuse_gbs / HBM_PEAK_GBS, 4),
                                     "traffic": traffic.get(f"k_fuse_{args.fuse_mode}"),
                                     "algorithmic_bytes_per_launch": int(fuse_bytes)}},
-            "parity": {"planted_integer_shifts_recovered": shifts_ok, "pairs_checked": int(n_pairs)},
+            "parity": {"planted_integer_shifts_recovered": shifts_ok, "pairs_checked": int(n_pairs),
+                       "solved_positions_are_the_fused_positions": positions_ok},
+            "position_solve": {"ms": round(1e3 * t_solve, 2), "where": "host, one core, on this rank's pair rows",
+                               "tree_edges": len(solved.tree)},
             "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
             "kernels": {n: {**{k: round(v, 3) for k, v in kernels[n].items()},
                             **({"hbm_frac": rooflines[n]["frac"]} if n in rooflines else {})} for n in kernels},
