@@ -179,3 +179,59 @@ def test_pyramid_levels_match_block_means(shape, levels):
         assert got[l].shape == want[l].shape, l
         assert got[l].dtype == want[l].dtype, l
         assert np.array_equal(got[l], want[l]), l
+
+
+@pytest.mark.parametrize("mode", ["overwrite", "feather"])
+def test_plate_of_wells_as_planes(fu, mode):
+    """A multi-well plate (many small independent grids): every (well, channel) is one plane of
+    a single fuse call, sized for the largest well; pairs of all wells go through one
+    registration call.  Each plane must equal that well fused on its own by the oracle."""
+    from image_stitcher_amd import registration, solve
+    from oracle import registration as oreg
+    wells, rows, cols, th, tw, ch = 6, 2, 3, 96, 128, 2
+    rng = np.random.default_rng(5)
+    tiles, yx, plane, ffidx, pair_idx, pair_dir = [], [], [], [], [], []
+    dims = []
+    per_well = rows * cols
+    for w in range(wells):
+        for c in range(ch):
+            g = synth.make_grid(300 + 10 * w + c, rows, cols, th, tw, overlap=0.125, jitter=2 + w % 2)
+            if c == 0:
+                well_yx = (g.true_yx - g.true_yx.min(axis=0)).astype(np.int32)
+                dims.append((int(well_yx[:, 0].max()) + th, int(well_yx[:, 1].max()) + tw))
+                pair_idx.append(g.pair_idx + len(tiles))
+                pair_dir.append(g.pair_dir)
+            else:   # other channels of a well are cut at the same positions from another scene
+                scene = synth.make_scene(900 + 10 * w + c, (rows - 1) * g.pitch_y + th + 8, (cols - 1) * g.pitch_x + tw + 8)
+                for t in range(per_well):
+                    y0, x0 = well_yx[t]
+                    g.tiles[t] = scene[y0:y0 + th, x0:x0 + tw]
+            tiles.extend(g.tiles)
+            yx.extend(well_yx)
+            plane.extend([w * ch + c] * per_well)
+            ffidx.extend([c] * per_well)
+    tiles, yx = np.stack(tiles), np.stack(yx)
+    pair_idx, pair_dir = np.concatenate(pair_idx), np.concatenate(pair_dir)
+    mh, mw = max(d[0] for d in dims), max(d[1] for d in dims)
+    ffs = np.stack([synth.make_flatfield(th, tw, amplitude=0.3 - 0.1 * c) for c in range(ch)])
+    # registration of every well's pairs in one call, then one solve per well
+    out, status = registration.register_pairs(tiles, pair_idx, pair_dir, 16, flatfield=None)
+    out, status = out.cpu().numpy(), status.cpu().numpy()
+    exp_out, exp_status = oreg.register_pairs(tiles, pair_idx, pair_dir, 16)
+    assert np.array_equal(status, exp_status) and np.array_equal(out[:, 1:], exp_out[:, 1:])
+    ppw = len(pair_idx) // wells
+    row, col = np.repeat(np.arange(rows), cols), np.tile(np.arange(cols), rows)
+    for w in range(wells):
+        sl = slice(w * ppw, (w + 1) * ppw)
+        first_tile = w * ch * per_well
+        res = solve.solve_positions(solve.grid_from_pairs(row, col, pair_idx[sl] - first_tile, pair_dir[sl], out[sl],
+                                                          status[sl]), th, tw, pou=8)
+        assert np.array_equal(np.stack([res.y_pos, res.x_pos], axis=1), yx[first_tile:first_tile + per_well])
+    got = _np(fu.fuse_tiles(tiles, yx, plane, wells * ch, mh, mw, flatfields=ffs, tile_ff=ffidx, mode=mode))
+    fuse = ofu.fuse_overwrite if mode == "overwrite" else ofu.fuse_feather
+    for w in range(wells):
+        sl = slice(w * ch * per_well, (w + 1) * ch * per_well)
+        h, wd = dims[w]
+        alone = fuse(tiles[sl], yx[sl], [p - w * ch for p in plane[sl]], ch, h, wd, flatfields=ffs, tile_ff=ffidx[sl])
+        assert np.array_equal(got[w * ch:(w + 1) * ch, :h, :wd], alone), w
+        assert (got[w * ch:(w + 1) * ch, h:] == 0).all() and (got[w * ch:(w + 1) * ch, :, wd:] == 0).all()
