@@ -149,6 +149,20 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
   return total;
 }
 
+// The same for a 32-bit value whose wave total fits 32 bits: one DPP add per step.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0u, v, CTRL, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+  v += dpp_u32<kDppXor1>(v);
+  v += dpp_u32<kDppXor2>(v);
+  v += dpp_u32<kDppHalfMirror>(v);
+  v += dpp_u32<kDppMirror>(v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
+}
+
 
 template <int CTRL>
 __device__ __forceinline__ Peak dpp_peak(const Peak& p) {
@@ -1863,7 +1877,29 @@ struct MomentAcc {
     add4(a.d[0], a.d[1], b.d[0], b.d[1]);
     add4(a.d[2], a.d[3], b.d[2], b.d[3]);
   }
-  // v[0..5) = sum a, sum b, sum a^2, sum b^2, sum ab
+  // one pixel pair
+  __device__ __forceinline__ void add1(unsigned a, unsigned b) { add4(a, 0u, b, 0u); }
+  // A call of add4 adds at most 2 * 4 * 255 * 255 = 520,200 to any plane, so after n calls per
+  // lane the sum of a plane over the 64 lanes of a wave fits 32 bits while n <= kWaveSteps32.
+  static constexpr int kWaveSteps32 = 128;
+  // Moments summed over the wave, the same in every lane; n = calls of add4 by the busiest lane.
+  __device__ __forceinline__ void wave_totals(int n, unsigned long long (&v)[5]) const {
+    if (n <= kWaveSteps32) {
+      v[0] = wave_sum_u32(a_l + (a_h << 8));
+      v[1] = wave_sum_u32(b_l + (b_h << 8));
+      v[2] = (unsigned long long)wave_sum_u32(aa_ll) + ((unsigned long long)wave_sum_u32(aa_lh) << 9) +
+             ((unsigned long long)wave_sum_u32(aa_hh) << 16);
+      v[3] = (unsigned long long)wave_sum_u32(bb_ll) + ((unsigned long long)wave_sum_u32(bb_lh) << 9) +
+             ((unsigned long long)wave_sum_u32(bb_hh) << 16);
+      v[4] = (unsigned long long)wave_sum_u32(ab_ll) + ((unsigned long long)wave_sum_u32(ab_x) << 8) +
+             ((unsigned long long)wave_sum_u32(ab_hh) << 16);
+    } else {
+      totals(v);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) v[i] = wave_sum_u64(v[i]);
+    }
+  }
+  // v[0..5) = sum a, sum b, sum a^2, sum b^2, sum ab of this lane
   __device__ __forceinline__ void totals(unsigned long long (&v)[5]) const {
     v[0] = (unsigned long long)a_l + ((unsigned long long)a_h << 8);
     v[1] = (unsigned long long)b_l + ((unsigned long long)b_h << 8);
@@ -1873,13 +1909,26 @@ struct MomentAcc {
   }
 };
 
-// Rows [r_begin, r_end) step r_step of two windows of ncols pixels; all 256 threads.
+// Rows [r_begin, r_end) step r_step of two windows of ncols pixels; all 256 threads.  Moments
+// summed over each wave come back in v (the same in every lane of a wave).
 __device__ __forceinline__ void moments_of_rows(const uint16_t* a, int64_t pa, const uint16_t* b, int64_t pb,
                                                 int r_begin, int r_end, int r_step, int ncols,
                                                 unsigned long long (&v)[5]) {
   MomentAcc acc;
-  unsigned long long tail[5] = {0, 0, 0, 0, 0};
   const int ngroups = ncols >> 3;
+  // The columns beyond the last whole group are taken one pixel pair per thread and step, eight
+  // threads to a row, apart from the rows' trips; the first step's pixels (all of them, when a
+  // workgroup has no more than 32 rows) are requested here, ahead of the groups, and used last.
+  const int ntail = ncols & 7;
+  const bool tail_lane = ((int)threadIdx.x & 7) < ntail;
+  const int64_t tail_col = 8 * ngroups + ((int)threadIdx.x & 7);
+  const int tail_row = r_begin + ((int)threadIdx.x >> 3) * r_step;
+  const bool tail_first = tail_lane && tail_row < r_end;
+  unsigned tail_a = 0, tail_b = 0;
+  if (tail_first) {
+    tail_a = a[(int64_t)tail_row * pa + tail_col];
+    tail_b = b[(int64_t)tail_row * pb + tail_col];
+  }
   int r = r_begin;
   {
     // two rows per trip: four 16-byte loads in flight per lane (three or four rows gain nothing more)
@@ -1897,18 +1946,6 @@ __device__ __forceinline__ void moments_of_rows(const uint16_t* a, int64_t pa, c
 #pragma unroll
         for (int k = 0; k < kRows; ++k) acc.add8(x[k], y[k]);
       }
-      const int e = 8 * ngroups + (int)threadIdx.x;
-      if (e < ncols) {
-#pragma unroll
-        for (int k = 0; k < kRows; ++k) {
-          const unsigned long long x = ra[(int64_t)k * r_step * pa + e], y = rb[(int64_t)k * r_step * pb + e];
-          tail[0] += x;
-          tail[1] += y;
-          tail[2] += x * x;
-          tail[3] += y * y;
-          tail[4] += x * y;
-        }
-      }
     }
   }
   for (; r < r_end; r += r_step) {
@@ -1916,28 +1953,23 @@ __device__ __forceinline__ void moments_of_rows(const uint16_t* a, int64_t pa, c
     const uint16_t* rb = b + (int64_t)r * pb;
     for (int g = threadIdx.x; g < ngroups; g += kThreads)
       acc.add8(*reinterpret_cast<const U16x8*>(ra + 8 * g), *reinterpret_cast<const U16x8*>(rb + 8 * g));
-    const int e = 8 * ngroups + (int)threadIdx.x;
-    if (e < ncols) {
-      const unsigned long long x = ra[e], y = rb[e];
-      tail[0] += x;
-      tail[1] += y;
-      tail[2] += x * x;
-      tail[3] += y * y;
-      tail[4] += x * y;
-    }
   }
-  acc.totals(v);
-#pragma unroll
-  for (int i = 0; i < 5; ++i) v[i] += tail[i];
+  if (tail_first) {
+    acc.add1(tail_a, tail_b);
+    for (int rr = tail_row + (kThreads >> 3) * r_step; rr < r_end; rr += (kThreads >> 3) * r_step)
+      acc.add1(a[(int64_t)rr * pa + tail_col], b[(int64_t)rr * pb + tail_col]);
+  }
+  const int nrows = r_end > r_begin ? (r_end - r_begin + r_step - 1) / r_step : 0;
+  const int steps = 2 * nrows * ((ngroups + kThreads - 1) / kThreads) +
+                    (ntail ? (nrows + (kThreads >> 3) - 1) / (kThreads >> 3) : 0);
+  acc.wave_totals(steps, v);
 }
 
-// Sum v[0..5) over the workgroup and add it to acc[0..5) with integer atomics
-// (exact and order independent).
+// Sum the wave totals v[0..5) over the workgroup and add them to acc[0..5) with integer
+// atomics (exact and order independent).
 __device__ __forceinline__ void reduce_moments(unsigned long long (&v)[5], unsigned long long* red,
                                                unsigned long long* acc) {
-#pragma unroll
-  for (int i = 0; i < 5; ++i) v[i] = wave_sum_u64(v[i]);
-  // one set of atomics per workgroup: four times as many (one per wave) contend enough on the
+  // v holds wave totals.  One set of atomics per workgroup: four times as many (one per wave) contend enough on the
   // candidate's five words to cost more than this barrier
   const int wave = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) {
@@ -1958,7 +1990,8 @@ __device__ __forceinline__ void reduce_moments(unsigned long long (&v)[5], unsig
 // workgroup b works for pair (b mod 8) + 8 * (...): every candidate of a pair is then summed
 // on one XCD, whose L2 keeps that pair's two strips while its ~30 overlaps are read from them.
 constexpr int kXcds = 8;
-__global__ __launch_bounds__(kThreads) void k_ncc_accumulate(const PairDesc* desc, const int8_t* status,
+constexpr int kShortStripRows = 256;  // the usual edge width: sizes the "small overlap" test below
+__global__ __launch_bounds__(kThreads, 8) void k_ncc_accumulate(const PairDesc* desc, const int8_t* status,
                                                              int pair0, int n_in_pass, const Cand* cand,
                                                              unsigned long long* acc) {
   __shared__ unsigned long long red[5 * kThreads / 64];
@@ -1969,18 +2002,27 @@ __global__ __launch_bounds__(kThreads) void k_ncc_accumulate(const PairDesc* des
   const int within = seq % kPerPair;
   const int ci = within / kNccChunks, chunk = within % kNccChunks;
   const int p = pair0 + pz;
-  if (status[p] != MISTITCH_PAIR_OK) return;
+  // three independent lookups, requested together ahead of the first test
+  const int8_t st = status[p];
   const Cand c = cand[(int64_t)p * kCandSlots + ci];
-  if (c.flag != 0) return;
   const PairDesc d = desc[p];
+  if (st != MISTITCH_PAIR_OK || c.flag != 0) return;
   const int ds = d.transposed ? c.x : c.y;
   const int dl = d.transposed ? c.y : c.x;
   const int s_lo = ds > 0 ? ds : 0, s_hi = d.S + (ds < 0 ? ds : 0);
   const int l_lo = dl > 0 ? dl : 0, l_hi = d.L + (dl < 0 ? dl : 0);
-  if (s_lo + chunk >= s_hi) return;
+  int first = s_lo + chunk, step = kNccChunks;
+  // an overlap of no more work than one workgroup's share of a full one is not worth the set-up
+  // and the reduction of eight: the first workgroup takes all its rows
+  if ((int64_t)(s_hi - s_lo) * ((l_hi - l_lo + 7) >> 3) <= (int64_t)kThreads * (kShortStripRows / kNccChunks)) {
+    if (chunk != 0) return;
+    first = s_lo;
+    step = 1;
+  }
+  if (first >= s_hi) return;
   unsigned long long v[5];
-  moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, s_lo + chunk, s_hi,
-                  kNccChunks, l_hi - l_lo, v);
+  moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, first, s_hi, step,
+                  l_hi - l_lo, v);
   reduce_moments(v, red, acc + ((int64_t)p * kCandSlots + ci) * 5);
 }
 
@@ -2097,8 +2139,6 @@ __device__ double block_ncc(const PairDesc& d, int ty, int tx, unsigned long lon
   unsigned long long v[5];
   moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, s_lo, s_hi, 1,
                   l_hi - l_lo, v);
-#pragma unroll
-  for (int i = 0; i < 5; ++i) v[i] = wave_sum_u64(v[i]);
   const int wave = threadIdx.x >> 6;
   __syncthreads();  // red may still be read from the previous call
   if ((threadIdx.x & 63) == 0) {
@@ -2762,12 +2802,22 @@ static int reserve_subpixel(mistitch_ctx* ctx, int n_pairs, int chunk, int abs_s
   return MISTITCH_OK;
 }
 
-static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, size_t staging_elems_per_pair,
+// The strips of ALL pairs of a call are staged by one launch, and their candidate overlaps summed by
+// one launch after the last pass, when the staging buffer for that stays modest; the transforms in
+// between go in passes of `chunk` pairs, which bound their workspace.  (Six short launches of the
+// candidate kernel spend a fifth of their time on their last few workgroups.)
+constexpr int64_t kStageAllBytes = 16ll << 30;
+constexpr int kStageAllPairs = 16384;  // grid dimensions of the staging kernels
+static bool stage_all_pairs(int n_pairs, int chunk, int64_t slot_elems) {
+  return n_pairs > chunk && n_pairs <= kStageAllPairs && (int64_t)n_pairs * slot_elems * 2 <= kStageAllBytes;
+}
+
+static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, int stage_slots, size_t staging_elems_per_pair,
                                 size_t spectrum_bytes_per_pair, size_t slab_bytes_per_pair, int partial_stride,
                                 RegWorkspace* ws) {
   int rc;
   if ((rc = ctx->desc.reserve((size_t)n_pairs * sizeof(PairDesc)))) return rc;
-  if ((rc = ctx->staging.reserve((size_t)chunk * staging_elems_per_pair * 2 + 256))) return rc;
+  if ((rc = ctx->staging.reserve((size_t)stage_slots * staging_elems_per_pair * 2 + 256))) return rc;
   if ((rc = ctx->spectrum.reserve((size_t)chunk * spectrum_bytes_per_pair))) return rc;
   if ((rc = ctx->slabs.reserve((size_t)chunk * slab_bytes_per_pair))) return rc;
   if ((rc = ctx->partial.reserve((size_t)chunk * partial_stride * sizeof(Peak)))) return rc;
@@ -2963,7 +3013,10 @@ extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int 
   const int chunk = max_pairs < ctx->pair_chunk ? max_pairs : ctx->pair_chunk;
   RegWorkspace ws;
   const size_t slab = std::max(a.slab_bytes, b.slab_bytes);
-  return reserve_registration(ctx, max_pairs, chunk, (size_t)w_left * tile_h * 2, spec, slab, pstride, &ws);
+  // slots large enough for either direction, as a call with a flatfield stages both
+  const int64_t slot_elems = 2 * std::max((int64_t)w_left * tile_h, (int64_t)w_top * tile_w);
+  const int stage_slots = stage_all_pairs(max_pairs, chunk, slot_elems) ? max_pairs : chunk;
+  return reserve_registration(ctx, max_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws);
 }
 
 // Body of mistitch_register_pairs / mistitch_register_pairs_flatfield (ff = NULL: tiles are used as they are).
@@ -2995,7 +3048,9 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
   // staging slot of a pair: its two strips; with a flatfield the top strips are staged as well
   const int64_t slot_elems =
       2 * (ff != nullptr ? std::max((int64_t)w_left * H, (int64_t)w_top * W) : (int64_t)w_left * H);
-  if ((rc = reserve_registration(ctx, n_pairs, chunk, (size_t)slot_elems, spec, slab, pstride, &ws))) return rc;
+  const bool stage_all = stage_all_pairs(n_pairs, chunk, slot_elems);
+  const int stage_slots = stage_all ? n_pairs : chunk;
+  if ((rc = reserve_registration(ctx, n_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws))) return rc;
   const bool subpixel = (flags & MISTITCH_REG_SUBPIXEL) != 0;
   if (subpixel) {
     if ((rc = reserve_subpixel(ctx, n_pairs, chunk, std::max(cfg_left.nblk, cfg_top.nblk),
@@ -3004,17 +3059,20 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
   }
   // 16-byte loads of tile rows need aligned rows; staging lines always are.
   const bool vec_top = aligned16(tiles) && (W % 8 == 0) && (tile_pitch % 8 == 0);
+  // may the top strips be read with 16-byte loads (with a flatfield they are staged too)
+  const bool vec_strips = ff != nullptr ? aligned16(ws.staging) && (W % 8 == 0) && (slot_elems % 8 == 0) &&
+                                              (((int64_t)w_top * W) % 8 == 0)
+                                        : vec_top;
   const int k = 2;  // peaks the candidate search consumes
 
   MS_LAUNCH(ctx, "k_setup_pairs", k_setup_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, tiles, tile_pitch, H, W, w_left,
-                     w_top, pair_idx, pair_dir, n_pairs, n_tiles, ws.staging, chunk, ws.desc, status, slot_elems,
+                     w_top, pair_idx, pair_dir, n_pairs, n_tiles, ws.staging, stage_slots, ws.desc, status, slot_elems,
                      ff != nullptr ? 1 : 0);
   if (ff == nullptr)
     MS_LAUNCH(ctx, "k_edge_stats", k_edge_stats, dim3(2, n_pairs), dim3(kThreads), 0, tiles, tile_pitch, H, W, w_left, w_top,
               pair_idx, pair_dir, status, 2e3);
-  for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {
-    const int n = std::min(chunk, n_pairs - pair0);
-    bool vec_strips = vec_top;  // may the top strips be read with 16-byte loads
+  // strips of pairs [pair0, pair0 + n) into the staging buffer
+  auto stage = [&](int pair0, int n) -> int {
     if (ff != nullptr) {
       // corrected strips of both directions go to the staging buffer; the featureless test reads them there
       const bool tiled = vec_top && H % 64 == 0 && W % 64 == 0;
@@ -3042,7 +3100,6 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
                     w_left, w_top, pair_idx, ws.desc, status, pair0, ff);
       }
       MS_LAUNCH(ctx, "k_edge_stats", k_edge_stats_staged, dim3(2, n), dim3(kThreads), 0, ws.desc, status, pair0, 2e3);
-      vec_strips = aligned16(ws.staging) && (W % 8 == 0) && (slot_elems % 8 == 0) && (((int64_t)w_top * W) % 8 == 0);
     } else if (vec_top && H % 64 == 0 && w_left % 64 == 0) {
       MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips64, dim3(H / 64, w_left / 64, 2 * n), dim3(256), 0, tiles,
                 tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
@@ -3050,6 +3107,16 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
       MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips, dim3((H + 31) / 32, (w_left + 31) / 32, 2 * n), dim3(32, 8), 0,
                 tiles, tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
     }
+    return MISTITCH_OK;
+  };
+  auto candidates = [&](int pair0, int n) {
+    MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(kXcds * ((n + kXcds - 1) / kXcds) * kCandSlots * kNccChunks),
+              dim3(kThreads), 0, ws.desc, status, pair0, n, ws.cand, ws.acc);
+  };
+  if (stage_all && (rc = stage(0, n_pairs))) return rc;
+  for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {
+    const int n = std::min(chunk, n_pairs - pair0);
+    if (!stage_all && (rc = stage(pair0, n))) return rc;
     if (same_shape) {
       // left strips come from the aligned staging buffer, top strips from the tiles (or from staging too)
       if ((rc = launch_any(ctx, cfg_left, f64, ws, status, pair0, n, -1, vec_strips, k, nullptr))) return rc;
@@ -3062,9 +3129,9 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
     if (subpixel)
       MS_LAUNCH(ctx, "k_ups_finish", k_ups_finish, dim3((n + 63) / 64), dim3(64), 0, ws.desc, status, pair0, n, ws.partial_ups,
                 ws.n_row_blocks, ws.n_up, ws.uf, ws.ups, ws.cand);
-    MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(kXcds * ((n + kXcds - 1) / kXcds) * kCandSlots * kNccChunks),
-              dim3(kThreads), 0, ws.desc, status, pair0, n, ws.cand, ws.acc);
+    if (!stage_all) candidates(pair0, n);
   }
+  if (stage_all) candidates(0, n_pairs);
   MS_LAUNCH(ctx, "k_finalize", k_finalize, dim3((n_pairs + 63) / 64), dim3(64), 0, ws.desc, status, n_pairs, ws.cand, ws.acc,
                      out, status, subpixel ? ws.ups : (const UpsState*)nullptr);
   MS_HIP(hipGetLastError());
@@ -3116,7 +3183,7 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   if ((rc = make_any_shape(ctx, S, L, f64, &cfg))) return rc;
   const int pstride = cfg.nblk * kMaxK;
   RegWorkspace ws;
-  if ((rc = reserve_registration(ctx, 1, 1, (size_t)S * L, cfg.spec_bytes, cfg.slab_bytes, pstride, &ws))) return rc;
+  if ((rc = reserve_registration(ctx, 1, 1, 1, (size_t)S * L, cfg.spec_bytes, cfg.slab_bytes, pstride, &ws))) return rc;
   if (sub_out != nullptr) {
     if ((rc = reserve_subpixel(ctx, 1, 1, cfg.nblk, cfg.n_stored, upsample, &ws))) return rc;
   }

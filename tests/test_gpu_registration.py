@@ -317,3 +317,37 @@ def test_register_pairs_with_fused_flatfield(reg, shape, edge, dt):
     ok = status == 0
     assert np.array_equal(out[ok, 1:], ref[ok, 1:])
     assert np.allclose(out[ok, 0], ref[ok, 0], rtol=0, atol=1e-12)
+
+
+def test_passes_smaller_than_the_call_give_the_same_rows(reg):
+    """More pairs than one pass holds: all strips are staged up front and the candidate overlaps
+    summed after the last pass.  Rows must equal those of a single pass, flatfield or not."""
+    import torch
+    from image_stitcher_amd import _lib
+    g = synth.make_grid(123, 3, 4, 256, 256, overlap=0.125, jitter=3)
+    ff = synth.make_flatfield(256, 256, amplitude=0.3)
+    small = _lib.Context(0, torch.cuda.current_stream().cuda_stream, pair_chunk=5)
+    for flat in (None, ff):
+        for sub in (False, True):
+            want, want_st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 32, flatfield=flat, subpixel=sub)
+            got, got_st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 32, flatfield=flat, subpixel=sub, ctx=small)
+            assert torch.equal(want_st, got_st)
+            assert torch.equal(want, got)
+    assert np.array_equal(want.cpu().numpy()[:, 1:].round().astype(np.int64), g.expected_shift)
+
+
+def test_tall_strips_take_the_wide_accumulators(reg):
+    """Strips of 1024 rows: a lane sums more steps than 32-bit wave totals can hold, so the
+    64-bit reduction runs; ragged widths exercise the columns beyond the last group of eight."""
+    g = synth.make_grid(321, 2, 2, 1024, 200, overlap=0.12, jitter=3)
+    out, status = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 1024)
+    exp, exp_st = oreg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 1024)
+    out, status = out.cpu().numpy(), status.cpu().numpy()
+    assert np.array_equal(status, exp_st)
+    assert np.array_equal(out[:, 1:], exp[:, 1:])
+    assert np.allclose(out[:, 0], exp[:, 0], rtol=0, atol=1e-12)
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, 65536, size=(1500, 701)).astype(np.uint16)
+    b = (a // 2 + rng.integers(0, 30000, size=a.shape)).astype(np.uint16)
+    assert abs(reg.ncc(a, b) - oreg.ncc(a, b)) < 1e-12
+    assert abs(reg.ncc(a[:, :5], b[:, :5]) - oreg.ncc(a[:, :5], b[:, :5])) < 1e-12
