@@ -27,7 +27,7 @@ FF_NONE, FF_F32, FF_F64 = 0, 1, 2
 
 EXPORTS = [
     "mistitch_version", "mistitch_last_error", "mistitch_create", "mistitch_destroy",
-    "mistitch_set_pair_chunk", "mistitch_reserve_registration", "mistitch_register_pairs",
+    "mistitch_set_pair_chunk", "mistitch_set_staging_limit", "mistitch_reserve_registration", "mistitch_register_pairs",
     "mistitch_pcm", "mistitch_pcm_topk", "mistitch_ncc", "mistitch_edge_variance",
     "mistitch_apply_flatfield", "mistitch_fuse", "mistitch_mip", "mistitch_synchronize",
     "mistitch_profile_enable", "mistitch_profile_collect", "mistitch_subpixel_shift",
@@ -55,6 +55,7 @@ def _load() -> C.CDLL:
         "mistitch_create": [i32, vp, C.POINTER(vp)],
         "mistitch_destroy": [vp],
         "mistitch_set_pair_chunk": [vp, i32],
+        "mistitch_set_staging_limit": [vp, i64],
         "mistitch_reserve_registration": [vp, i32, i32, i32, i32, u32],
         "mistitch_register_pairs": [vp, vp, i32, i32, i32, i64, vp, vp, i32, i32, u32, vp, vp],
         "mistitch_register_pairs_flatfield": [vp, vp, i32, i32, i32, i64, vp, i32, vp, vp, i32, i32, u32, vp, vp],
@@ -117,6 +118,9 @@ class Context:
 
     def set_pair_chunk(self, n: int) -> None:
         check(lib.mistitch_set_pair_chunk(self.handle, int(n)))
+
+    def set_staging_limit(self, n_bytes: int) -> None:
+        check(lib.mistitch_set_staging_limit(self.handle, int(n_bytes)))
 
     def set_upsample_factor(self, u: int) -> None:
         check(lib.mistitch_set_upsample_factor(self.handle, int(u)))

@@ -43,6 +43,13 @@ extern "C" int mistitch_set_pair_chunk(mistitch_ctx* ctx, int pairs_per_pass) {
   return MISTITCH_OK;
 }
 
+extern "C" int mistitch_set_staging_limit(mistitch_ctx* ctx, int64_t bytes) {
+  MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
+  MS_REQUIRE(bytes >= 0, MISTITCH_ERR_ARG, "staging limit must be >= 0");
+  ctx->staging_limit = bytes;
+  return MISTITCH_OK;
+}
+
 extern "C" int mistitch_synchronize(mistitch_ctx* ctx) {
   MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
   MS_HIP(hipSetDevice(ctx->device));

@@ -150,6 +150,7 @@ struct mistitch_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   int pair_chunk = 128;  // pairs processed per pipeline pass (bounds the FFT workspace)
+  int64_t staging_limit = 4ll << 30;  // strips of all pairs of a call are staged at once up to this many bytes
   int upsample_factor = 100;  // subpixel grid: 1 / upsample_factor pixels
   std::map<long long, mistitch::FftPlanHost> plans;  // key = n * 2 + (is_f64)
   mistitch::DevBuf desc, staging, spectrum, slabs, partial, peaks, cand, acc, misc, bins, flags, ups;

@@ -2806,10 +2806,9 @@ static int reserve_subpixel(mistitch_ctx* ctx, int n_pairs, int chunk, int abs_s
 // one launch after the last pass, when the staging buffer for that stays modest; the transforms in
 // between go in passes of `chunk` pairs, which bound their workspace.  (Six short launches of the
 // candidate kernel spend a fifth of their time on their last few workgroups.)
-constexpr int64_t kStageAllBytes = 16ll << 30;
 constexpr int kStageAllPairs = 16384;  // grid dimensions of the staging kernels
-static bool stage_all_pairs(int n_pairs, int chunk, int64_t slot_elems) {
-  return n_pairs > chunk && n_pairs <= kStageAllPairs && (int64_t)n_pairs * slot_elems * 2 <= kStageAllBytes;
+static bool stage_all_pairs(const mistitch_ctx* ctx, int n_pairs, int chunk, int64_t slot_elems) {
+  return n_pairs > chunk && n_pairs <= kStageAllPairs && (int64_t)n_pairs * slot_elems * 2 <= ctx->staging_limit;
 }
 
 static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, int stage_slots, size_t staging_elems_per_pair,
@@ -3015,7 +3014,7 @@ extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int 
   const size_t slab = std::max(a.slab_bytes, b.slab_bytes);
   // slots large enough for either direction, as a call with a flatfield stages both
   const int64_t slot_elems = 2 * std::max((int64_t)w_left * tile_h, (int64_t)w_top * tile_w);
-  const int stage_slots = stage_all_pairs(max_pairs, chunk, slot_elems) ? max_pairs : chunk;
+  const int stage_slots = stage_all_pairs(ctx, max_pairs, chunk, slot_elems) ? max_pairs : chunk;
   return reserve_registration(ctx, max_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws);
 }
 
@@ -3048,7 +3047,7 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
   // staging slot of a pair: its two strips; with a flatfield the top strips are staged as well
   const int64_t slot_elems =
       2 * (ff != nullptr ? std::max((int64_t)w_left * H, (int64_t)w_top * W) : (int64_t)w_left * H);
-  const bool stage_all = stage_all_pairs(n_pairs, chunk, slot_elems);
+  const bool stage_all = stage_all_pairs(ctx, n_pairs, chunk, slot_elems);
   const int stage_slots = stage_all ? n_pairs : chunk;
   if ((rc = reserve_registration(ctx, n_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws))) return rc;
   const bool subpixel = (flags & MISTITCH_REG_SUBPIXEL) != 0;

@@ -69,6 +69,14 @@ int mistitch_destroy(mistitch_ctx* ctx);
  * Default 128. */
 int mistitch_set_pair_chunk(mistitch_ctx* ctx, int pairs_per_pass);
 
+/* A call with more pairs than one pass stages the edge strips of ALL its pairs first (one
+ * launch) and sums the candidate overlaps once after the last pass, when that staging buffer
+ * (2 strips per pair: 2 MiB at edge width 256 on 2048-pixel tiles) stays within `bytes`;
+ * otherwise strips are staged and candidates summed pass by pass, with the same results.
+ * Default 4 GiB; 0 = always pass by pass.  No counterpart in the reference, whose pair loop
+ * is serial. */
+int mistitch_set_staging_limit(mistitch_ctx* ctx, int64_t bytes);
+
 /* Pre-size all workspaces so that later mistitch_register_pairs calls with
  * shapes up to these do not allocate. */
 int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int edge_width,

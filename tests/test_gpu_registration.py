@@ -327,12 +327,15 @@ def test_passes_smaller_than_the_call_give_the_same_rows(reg):
     g = synth.make_grid(123, 3, 4, 256, 256, overlap=0.125, jitter=3)
     ff = synth.make_flatfield(256, 256, amplitude=0.3)
     small = _lib.Context(0, torch.cuda.current_stream().cuda_stream, pair_chunk=5)
+    by_pass = _lib.Context(0, torch.cuda.current_stream().cuda_stream, pair_chunk=5)
+    by_pass.set_staging_limit(0)    # strips staged and candidates summed pass by pass
     for flat in (None, ff):
         for sub in (False, True):
             want, want_st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 32, flatfield=flat, subpixel=sub)
-            got, got_st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 32, flatfield=flat, subpixel=sub, ctx=small)
-            assert torch.equal(want_st, got_st)
-            assert torch.equal(want, got)
+            for ctx in (small, by_pass):
+                got, got_st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 32, flatfield=flat, subpixel=sub, ctx=ctx)
+                assert torch.equal(want_st, got_st)
+                assert torch.equal(want, got)
     assert np.array_equal(want.cpu().numpy()[:, 1:].round().astype(np.int64), g.expected_shift)
 
 
