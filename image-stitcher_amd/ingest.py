@@ -133,3 +133,123 @@ def register_streaming(fill: Fill, n_rows: int, n_cols: int, tile_h: int, tile_w
         status[sel] = s
     compute.wait_stream(stager.copy_stream)
     return tiles, out, status
+
+
+# ------------------------------------------------------------------------------------------------
+# fusion in mosaic row bands: upload -> fuse -> download, three streams, two buffers each
+# ------------------------------------------------------------------------------------------------
+FillTiles = Callable[[np.ndarray, np.ndarray], None]
+"""``fill(indices, dst)`` writes the tiles ``indices`` (ascending = placement order) into ``dst``
+([len(indices), H, W] uint16, pinned)."""
+
+Drain = Callable[[int, int, np.ndarray], None]
+"""``drain(row0, row1, src)`` consumes mosaic rows [row0, row1) of every plane from ``src``
+([n_planes, row1 - row0, mosaic_w] uint16, pinned; valid only during the call)."""
+
+
+def plan_mosaic_bands(tile_y: Sequence[int], tile_h: int, mosaic_h: int, band_rows: int,
+                      rows: Optional[Tuple[int, int]] = None) -> List[Tuple[int, int, np.ndarray]]:
+    """(row0, row1, indices of the tiles that touch the band, ascending) for consecutive bands of
+    ``band_rows`` mosaic rows over ``rows`` (default: the whole mosaic).  A tile that straddles a
+    band edge is listed, and uploaded, for both bands."""
+    if band_rows < 1:
+        raise ValueError("band_rows must be >= 1")
+    lo, hi = (0, mosaic_h) if rows is None else (int(rows[0]), int(rows[1]))
+    y = np.asarray(tile_y, dtype=np.int64)
+    out = []
+    for r0 in range(lo, hi, band_rows):
+        r1 = min(hi, r0 + band_rows)
+        out.append((r0, r1, np.nonzero((y < r1) & (y + tile_h > r0))[0]))
+    return out
+
+
+def fuse_streaming(fill: FillTiles, drain: Drain, tile_yx, tile_plane, n_planes: int, tile_h: int, tile_w: int,
+                   mosaic_h: int, mosaic_w: int, band_rows: int = 4096, flatfields=None, tile_ff=None,
+                   mode: str = "overwrite", rows: Optional[Tuple[int, int]] = None, ctx=None, device=None,
+                   workspace: Optional[dict] = None) -> int:
+    """Fuse a mosaic that need not fit on the device, nor its tiles: per band of mosaic rows the
+    touching tiles go up through pinned memory, the band is fused as a mosaic of its own (tile
+    rows shifted by the band's first row) and comes down through pinned memory, the three steps
+    of neighbouring bands overlapping.  Tiles are in placement order, as for ``fuse_tiles``; the
+    bands handed to ``drain`` equal the rows of the one-shot mosaic.  Returns the number of bands.
+    ``workspace``: a dict that keeps the pinned and device buffers between calls of the same
+    geometry (pinning gigabytes takes longer than moving them)."""
+    import torch
+    from . import fusion
+    yx = np.asarray(tile_yx, dtype=np.int32).reshape(-1, 2)
+    plane = np.asarray(tile_plane, dtype=np.int32).reshape(-1)
+    ffi = None if tile_ff is None else np.asarray(tile_ff, dtype=np.int32).reshape(-1)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    bands = plan_mosaic_bands(yx[:, 0], tile_h, mosaic_h, band_rows, rows)
+    if not bands:
+        return 0
+    max_tiles = max(1, max(len(b[2]) for b in bands))
+    max_rows = max(b[1] - b[0] for b in bands)
+    if flatfields is not None and not isinstance(flatfields, torch.Tensor):
+        flatfields = torch.from_numpy(np.ascontiguousarray(flatfields)).to(dev)
+    band_px = n_planes * max_rows * mosaic_w    # flat: a band is viewed as [n_planes, its rows, mosaic_w]
+    key = (max_tiles, tile_h, tile_w, band_px, str(dev))
+    ws = workspace if workspace is not None else {}
+    if ws.get("key") != key:
+        ws.clear()
+        ws["key"] = key
+        ws["pin_in"] = [torch.empty((max_tiles, tile_h, tile_w), dtype=torch.int16).pin_memory() for _ in range(2)]
+        ws["dev_in"] = [torch.empty((max_tiles, tile_h, tile_w), dtype=torch.int16, device=dev) for _ in range(2)]
+        ws["dev_out"] = [torch.empty((band_px,), dtype=torch.int16, device=dev) for _ in range(2)]
+        ws["pin_out"] = [torch.empty((band_px,), dtype=torch.int16).pin_memory() for _ in range(2)]
+    pin_in, dev_in, dev_out, pin_out = ws["pin_in"], ws["dev_in"], ws["dev_out"], ws["pin_out"]
+    s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    compute = torch.cuda.current_stream(dev)
+    up_done = [None, None]      # H2D of the band using input pair k has finished (pinned side reusable)
+    fused = [None, None]        # fuse of that band has finished (device input reusable, device output ready)
+    down_done = [None, None]    # D2H of that band has finished (device output reusable, pinned output ready)
+    pending = [None, None]      # (row0, row1) waiting in pin_out[k]
+
+    def drain_slot(k):
+        if pending[k] is not None:
+            down_done[k].synchronize()
+            r0, r1 = pending[k]
+            h = r1 - r0
+            drain(r0, r1, pin_out[k][:n_planes * h * mosaic_w].view(n_planes, h, mosaic_w).numpy().view(np.uint16))
+            pending[k] = None
+
+    for i, (r0, r1, idx) in enumerate(bands):
+        k = i & 1
+        n, h = len(idx), r1 - r0
+        drain_slot(k)                           # frees pin_out[k]; its D2H also released dev_out[k]
+        if up_done[k] is not None:
+            up_done[k].synchronize()
+        if n:
+            fill(idx, pin_in[k][:n].numpy().view(np.uint16))
+        with torch.cuda.stream(s_in):
+            if fused[k] is not None:
+                s_in.wait_event(fused[k])       # the band that last read dev_in[k]
+            if n:
+                dev_in[k][:n].copy_(pin_in[k][:n], non_blocking=True)
+            up_done[k] = torch.cuda.Event()
+            up_done[k].record(s_in)
+        # the band's small index arrays go up from pinned memory without stalling this thread
+        local_yx = yx[idx].copy()
+        local_yx[:, 0] -= r0
+        to_dev = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(dev, non_blocking=True))
+        d_yx, d_plane = to_dev(local_yx), to_dev(plane[idx])
+        d_ff = None if ffi is None else to_dev(ffi[idx])
+        compute.wait_event(up_done[k])
+        if down_done[k] is not None:
+            compute.wait_event(down_done[k])    # dev_out[k] has been read out
+        band_out = dev_out[k][:n_planes * h * mosaic_w].view(n_planes, h, mosaic_w)
+        fusion.fuse_tiles(dev_in[k][:n].view(torch.uint16), d_yx, d_plane, n_planes, h, mosaic_w,
+                          flatfields=flatfields, tile_ff=d_ff, mode=mode, out=band_out.view(torch.uint16), ctx=ctx)
+        fused[k] = torch.cuda.Event()
+        fused[k].record(compute)
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(fused[k])
+            pin_out[k][:n_planes * h * mosaic_w].copy_(dev_out[k][:n_planes * h * mosaic_w], non_blocking=True)
+            down_done[k] = torch.cuda.Event()
+            down_done[k].record(s_out)
+        pending[k] = (r0, r1)
+    drain_slot(len(bands) & 1)
+    drain_slot((len(bands) + 1) & 1)
+    compute.wait_stream(s_in)
+    compute.wait_stream(s_out)
+    return len(bands)

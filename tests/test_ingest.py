@@ -47,3 +47,43 @@ def test_streamed_registration_equals_the_resident_one(per):
         assert torch.equal(tiles.cpu(), torch.from_numpy(g.tiles.view(np.int16)).view(torch.uint16))
         assert torch.equal(status, want_st) and torch.equal(out, want)
     assert np.array_equal(out.cpu().numpy()[:, 1:].astype(np.int64), g.expected_shift)
+
+
+def test_mosaic_bands_cover_the_rows_and_list_straddling_tiles_twice():
+    y = np.array([0, 3, 100, 190, 200, 390])
+    bands = ingest.plan_mosaic_bands(y, 100, 490, 128)
+    assert [(a, b) for a, b, _ in bands] == [(0, 128), (128, 256), (256, 384), (384, 490)]
+    assert [idx.tolist() for _, _, idx in bands] == [[0, 1, 2], [2, 3, 4], [3, 4], [5]]
+    assert [(a, b) for a, b, _ in ingest.plan_mosaic_bands(y, 100, 490, 200, rows=(100, 450))] == [(100, 300), (300, 450)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["overwrite", "feather"])
+@pytest.mark.parametrize("band_rows", [64, 100, 1000])
+def test_streamed_fusion_equals_the_one_shot_mosaic(mode, band_rows):
+    from image_stitcher_amd import fusion
+    g = synth.make_grid(43, 4, 3, 96, 136, overlap=0.15, jitter=3)
+    ch = 2
+    other = synth.make_grid(44, 4, 3, 96, 136, overlap=0.15, jitter=3)
+    tiles = np.concatenate([g.tiles, other.tiles])
+    yx = np.tile((g.true_yx - g.true_yx.min(axis=0)).astype(np.int32), (ch, 1))
+    plane = np.repeat(np.arange(ch), 12).astype(np.int32)
+    ffs = np.stack([synth.make_flatfield(96, 136, amplitude=0.3 - 0.1 * c) for c in range(ch)])
+    mh, mw = int(yx[:, 0].max()) + 96, int(yx[:, 1].max()) + 136
+    want = fusion.fuse_tiles(tiles, yx, plane, ch, mh, mw, flatfields=ffs, tile_ff=plane, mode=mode).cpu().numpy()
+    got = np.full((ch, mh, mw), 0xABCD, dtype=np.uint16)
+    seen = []
+
+    def fill(idx, dst):
+        assert (np.diff(idx) > 0).all() and dst.shape == (len(idx), 96, 136)
+        np.copyto(dst, tiles[idx])
+
+    def drain(r0, r1, src):
+        seen.append((r0, r1))
+        got[:, r0:r1] = src
+
+    n = ingest.fuse_streaming(fill, drain, yx, plane, ch, 96, 136, mh, mw, band_rows=band_rows, flatfields=ffs,
+                              tile_ff=plane, mode=mode)
+    assert n == len(seen) == -(-mh // band_rows)
+    assert seen == [(r, min(mh, r + band_rows)) for r in range(0, mh, band_rows)]
+    assert np.array_equal(got, want)
