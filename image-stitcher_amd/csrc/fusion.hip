@@ -51,6 +51,14 @@ struct __attribute__((packed, aligned(2))) Px8 {
   do {                                    \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) MS_PIN((p).v[i_]); \
   } while (0)
+// Mosaic pixels are written once and never read back: stored non-temporal they leave the caches to
+// the flatfield planes, which every tile reads again (2 % with a flatfield, nothing without).  The
+// same hint on the tile pixel loads costs time: neighbouring lanes' unaligned 16-byte reads share lines.
+typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_px8_stream(uint16_t* p, const Px8& v) {  // p 16-byte aligned
+  __builtin_nontemporal_store(nt_u4{v.d[0], v.d[1], v.d[2], v.d[3]}, reinterpret_cast<nt_u4*>(p));
+}
+
 struct __attribute__((packed, aligned(4))) F8 {
   float v[8];
 };
@@ -602,12 +610,12 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
       const int x = x0 + 512 * r;
       if (k == 1) {
         if constexpr (FF == MISTITCH_FF_NONE)
-          *reinterpret_cast<Px8*>(rowp + x) = v[r];
+          store_px8_stream(rowp + x, v[r]);
         else
-          *reinterpret_cast<Px8*>(rowp + x) = corrected8_packed<FF, SAFE>(v[r], f32[FF == MISTITCH_FF_F32 ? r : 0],
-                                                                           f64[FF == MISTITCH_FF_F64 ? r : 0]);
+          store_px8_stream(rowp + x, corrected8_packed<FF, SAFE>(v[r], f32[FF == MISTITCH_FF_F32 ? r : 0],
+                                                                  f64[FF == MISTITCH_FF_F64 ? r : 0]));
       } else if (k == 0) {
-        *reinterpret_cast<Px8*>(rowp + x) = Px8{{0u, 0u, 0u, 0u}};
+        store_px8_stream(rowp + x, Px8{{0u, 0u, 0u, 0u}});
       } else if (k == 2) {
         // queued for the whole workgroup: these groups cluster in the overlap bands, and
         // handled in place they would stall every wave that owns a few
@@ -651,7 +659,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
         ci[2] = (int)((f >> (4 * (cnt - 3))) & 15u);
         ci[3] = cnt == 4 ? (int)(f & 15u) : ci[0];
       }
-      *reinterpret_cast<Px8*>(rowp + x) = blend_group<MODE, FF, SAFE>(y, x, cnt, ci, list, tiles, H, W, flatfields);
+      store_px8_stream(rowp + x, blend_group<MODE, FF, SAFE>(y, x, cnt, ci, list, tiles, H, W, flatfields));
     }
   }
   const unsigned n_generic = queue_len[1];
