@@ -2065,64 +2065,62 @@ __device__ double ncc_from_moments(unsigned long long n, unsigned long long sa, 
   return r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);
 }
 
-// One thread per pair walks the candidates in evaluation order.
-__global__ void k_finalize(const PairDesc* desc, const int8_t* status_in, int n_pairs, const Cand* cand,
-                           const unsigned long long* acc, double* out, int8_t* status, const UpsState* ups) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per pair: lane c scores candidate c, lane kNumCand the subpixel estimate; the winner is the
+// first candidate in evaluation order that no other beats (the serial walk's strict ">").
+static_assert(kNumCand < 64, "one lane per candidate plus one");
+__global__ __launch_bounds__(256) void k_finalize(const PairDesc* desc, const int8_t* status_in, int n_pairs,
+                                                  const Cand* cand, const unsigned long long* acc, double* out,
+                                                  int8_t* status, const UpsState* ups) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (p >= n_pairs) return;
   if (status_in[p] != MISTITCH_PAIR_OK) {
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
-    out[3 * p] = out[3 * p + 1] = out[3 * p + 2] = nan;
+    if (lane < 3) out[3 * p + lane] = nan;
     return;
   }
   const PairDesc d = desc[p];
-  double best = -INFINITY;
-  int by = 0, bx = 0;
-  double vals[kNumCand];
-  for (int c = 0; c < kNumCand; ++c) {
-    const Cand k = cand[(int64_t)p * kCandSlots + c];
-    double v;
-    if (k.flag == 1) {
-      vals[c] = -INFINITY;
-      continue;  // empty overlap: not evaluated at all
-    } else if (k.flag == 2) {
-      v = -INFINITY;
-    } else if (k.flag == 3) {
-      v = vals[k.dup_of];
-    } else {
-      const unsigned long long* m = acc + ((int64_t)p * kCandSlots + c) * 5;
+  const bool has_ups = ups != nullptr && ups[p].valid;
+  const bool mine = lane < kNumCand || (lane == kNumCand && has_ups);
+  Cand k{};
+  double v = -INFINITY;
+  bool evaluated = false;  // an empty overlap (flag 1) is not evaluated at all
+  if (mine) {
+    k = cand[(int64_t)p * kCandSlots + lane];
+    evaluated = k.flag != 1;
+    if (k.flag == 0) {
+      const unsigned long long* m = acc + ((int64_t)p * kCandSlots + lane) * 5;
       const int ay = k.y < 0 ? -k.y : k.y, ax = k.x < 0 ? -k.x : k.x;
       const unsigned long long n = (unsigned long long)(d.img_h - ay) * (unsigned long long)(d.img_w - ax);
       v = ncc_from_moments(n, m[0], m[1], m[2], m[3], m[4]);
     }
-    vals[c] = v;
-    if (v > best) {
-      best = v;
-      by = k.y;
-      bx = k.x;
-    }
   }
-  double oy = (double)by, ox = (double)bx;
-  if (ups != nullptr && ups[p].valid) {
-    // The subpixel estimate is scored at its rounded position and is listed BEFORE the
-    // discrete result (_translation_computation.py:1232-1313): it wins unless strictly worse.
-    const Cand k = cand[(int64_t)p * kCandSlots + kNumCand];
-    if (k.flag == 0) {
-      const unsigned long long* m = acc + ((int64_t)p * kCandSlots + kNumCand) * 5;
-      const int ay = k.y < 0 ? -k.y : k.y, ax = k.x < 0 ? -k.x : k.x;
-      const unsigned long long n = (unsigned long long)(d.img_h - ay) * (unsigned long long)(d.img_w - ax);
-      const double v = ncc_from_moments(n, m[0], m[1], m[2], m[3], m[4]);
-      if (v != -INFINITY && v >= best) {
-        best = v;
-        oy = d.transposed ? ups[p].sub_l : ups[p].sub_s;
-        ox = d.transposed ? ups[p].sub_s : ups[p].sub_l;
-      }
-    }
+  // a duplicate takes the value of the candidate it repeats (always an earlier, scored one)
+  const double of_dup = __shfl(v, (mine && k.flag == 3) ? k.dup_of : lane);
+  if (mine && k.flag == 3) v = of_dup;
+  const bool discrete = lane < kNumCand && evaluated;
+  double best = discrete ? v : -INFINITY;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) best = fmax(best, __shfl_xor(best, off));
+  const unsigned long long at_best = __ballot(discrete && v == best && best != -INFINITY);
+  const int win = at_best ? __builtin_ctzll(at_best) : -1;
+  const int by = __shfl(k.y, win < 0 ? 0 : win), bx = __shfl(k.x, win < 0 ? 0 : win);
+  double oy = win < 0 ? 0.0 : (double)by, ox = win < 0 ? 0.0 : (double)bx;
+  // The subpixel estimate is scored at its rounded position and is listed BEFORE the
+  // discrete result (_translation_computation.py:1232-1313): it wins unless strictly worse.
+  const double v_ups = __shfl(v, kNumCand);
+  const int flag_ups = __shfl((int)k.flag, kNumCand);
+  if (has_ups && flag_ups == 0 && v_ups != -INFINITY && v_ups >= best) {
+    best = v_ups;
+    oy = d.transposed ? ups[p].sub_l : ups[p].sub_s;
+    ox = d.transposed ? ups[p].sub_s : ups[p].sub_l;
   }
-  out[3 * p] = best;
-  out[3 * p + 1] = oy + (double)d.off_y;
-  out[3 * p + 2] = ox + (double)d.off_x;
-  if (best == -INFINITY) status[p] = MISTITCH_PAIR_NO_CANDIDATE;
+  if (lane == 0) {
+    out[3 * p] = best;
+    out[3 * p + 1] = oy + (double)d.off_y;
+    out[3 * p + 2] = ox + (double)d.off_x;
+    if (best == -INFINITY) status[p] = MISTITCH_PAIR_NO_CANDIDATE;
+  }
 }
 
 // NCC of the overlap of one pair's strips under the strip-relative shift (ty, tx), computed
@@ -3131,7 +3129,7 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
     if (!stage_all) candidates(pair0, n);
   }
   if (stage_all) candidates(0, n_pairs);
-  MS_LAUNCH(ctx, "k_finalize", k_finalize, dim3((n_pairs + 63) / 64), dim3(64), 0, ws.desc, status, n_pairs, ws.cand, ws.acc,
+  MS_LAUNCH(ctx, "k_finalize", k_finalize, dim3((n_pairs + 3) / 4), dim3(256), 0, ws.desc, status, n_pairs, ws.cand, ws.acc,
                      out, status, subpixel ? ws.ups : (const UpsState*)nullptr);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
