@@ -170,7 +170,9 @@ def fuse_streaming(fill: FillTiles, drain: Drain, tile_yx, tile_plane, n_planes:
     """Fuse a mosaic that need not fit on the device, nor its tiles: per band of mosaic rows the
     touching tiles go up through pinned memory, the band is fused as a mosaic of its own (tile
     rows shifted by the band's first row) and comes down through pinned memory, the three steps
-    of neighbouring bands overlapping.  Tiles are in placement order, as for ``fuse_tiles``; the
+    of neighbouring bands overlapping.  A tile that straddles a band edge is decoded and sent
+    once: the next band takes it from the previous band's device buffer.
+    Tiles are in placement order, as for ``fuse_tiles``; the
     bands handed to ``drain`` equal the rows of the one-shot mosaic.  Returns the number of bands.
     ``workspace``: a dict that keeps the pinned and device buffers between calls of the same
     geometry (pinning gigabytes takes longer than moving them)."""
@@ -195,9 +197,13 @@ def fuse_streaming(fill: FillTiles, drain: Drain, tile_yx, tile_plane, n_planes:
         ws["key"] = key
         ws["pin_in"] = [torch.empty((max_tiles, tile_h, tile_w), dtype=torch.int16).pin_memory() for _ in range(2)]
         ws["dev_in"] = [torch.empty((max_tiles, tile_h, tile_w), dtype=torch.int16, device=dev) for _ in range(2)]
+        ws["dev_new"] = torch.empty((max_tiles, tile_h, tile_w), dtype=torch.int16, device=dev)
         ws["dev_out"] = [torch.empty((band_px,), dtype=torch.int16, device=dev) for _ in range(2)]
         ws["pin_out"] = [torch.empty((band_px,), dtype=torch.int16).pin_memory() for _ in range(2)]
     pin_in, dev_in, dev_out, pin_out = ws["pin_in"], ws["dev_in"], ws["dev_out"], ws["pin_out"]
+    dev_new = ws["dev_new"]
+    prev_idx = np.zeros((0,), dtype=np.int64)
+    to_dev = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(dev, non_blocking=True))
     s_in, s_out = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
     compute = torch.cuda.current_stream(dev)
     up_done = [None, None]      # H2D of the band using input pair k has finished (pinned side reusable)
@@ -219,19 +225,27 @@ def fuse_streaming(fill: FillTiles, drain: Drain, tile_yx, tile_plane, n_planes:
         drain_slot(k)                           # frees pin_out[k]; its D2H also released dev_out[k]
         if up_done[k] is not None:
             up_done[k].synchronize()
-        if n:
-            fill(idx, pin_in[k][:n].numpy().view(np.uint16))
+        # tiles the previous band already brought up are copied across on the device
+        kept = np.isin(idx, prev_idx)
+        new_at, kept_at = np.nonzero(~kept)[0], np.nonzero(kept)[0]
+        kept_from = np.searchsorted(prev_idx, idx[kept_at])
+        n_new = len(new_at)
+        if n_new:
+            fill(idx[new_at], pin_in[k][:n_new].numpy().view(np.uint16))
         with torch.cuda.stream(s_in):
             if fused[k] is not None:
                 s_in.wait_event(fused[k])       # the band that last read dev_in[k]
-            if n:
-                dev_in[k][:n].copy_(pin_in[k][:n], non_blocking=True)
+            if n_new:
+                dev_new[:n_new].copy_(pin_in[k][:n_new], non_blocking=True)
+                dev_in[k].index_copy_(0, to_dev(new_at), dev_new[:n_new])
+            if len(kept_at):
+                dev_in[k].index_copy_(0, to_dev(kept_at), dev_in[k ^ 1].index_select(0, to_dev(kept_from)))
             up_done[k] = torch.cuda.Event()
             up_done[k].record(s_in)
+        prev_idx = idx
         # the band's small index arrays go up from pinned memory without stalling this thread
         local_yx = yx[idx].copy()
         local_yx[:, 0] -= r0
-        to_dev = (lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(dev, non_blocking=True))
         d_yx, d_plane = to_dev(local_yx), to_dev(plane[idx])
         d_ff = None if ffi is None else to_dev(ffi[idx])
         compute.wait_event(up_done[k])

@@ -74,8 +74,11 @@ def test_streamed_fusion_equals_the_one_shot_mosaic(mode, band_rows):
     got = np.full((ch, mh, mw), 0xABCD, dtype=np.uint16)
     seen = []
 
+    filled = []
+
     def fill(idx, dst):
         assert (np.diff(idx) > 0).all() and dst.shape == (len(idx), 96, 136)
+        filled.extend(idx.tolist())
         np.copyto(dst, tiles[idx])
 
     def drain(r0, r1, src):
@@ -87,3 +90,4 @@ def test_streamed_fusion_equals_the_one_shot_mosaic(mode, band_rows):
     assert n == len(seen) == -(-mh // band_rows)
     assert seen == [(r, min(mh, r + band_rows)) for r in range(0, mh, band_rows)]
     assert np.array_equal(got, want)
+    assert sorted(filled) == list(range(len(tiles)))      # every tile decoded and sent once, straddling or not
