@@ -267,3 +267,36 @@ def fuse_streaming(fill: FillTiles, drain: Drain, tile_yx, tile_plane, n_planes:
     compute.wait_stream(s_in)
     compute.wait_stream(s_out)
     return len(bands)
+
+
+def stitch_streaming(fill_registration: Fill, fill_tiles: FillTiles, drain: Drain, n_rows: int, n_cols: int,
+                     tile_h: int, tile_w: int, n_planes: int, tile_plane, tile_grid_index,
+                     edge_width: int = 256, pou: float = 3, ncc_threshold: float = 0.5, flatfields=None, tile_ff=None,
+                     registration_flatfield=None, mode: str = "overwrite", band_rows: int = 4096,
+                     rows_per_band: int = 2, subpixel: bool = False):
+    """The whole path for one region, host memory to host memory: the registration channel goes up
+    and is registered band by band, the pair rows are solved into tile positions on the host, and
+    every plane is fused at those positions band by band.  What ``register_tiles_batched`` followed
+    by ``Stitcher.stitch_region`` do in the reference (tile_registration.py:641-1221,
+    stitcher.py:313-405), with the stage coordinates replaced by the solved positions.
+
+    fill_registration  Fill for the row-major grid of the registration channel
+    fill_tiles         FillTiles for all tiles to fuse, in placement order
+    tile_plane         [T] destination plane of every tile to fuse
+    tile_grid_index    [T] grid tile (row * n_cols + col) each of them belongs to
+    Returns (PositionSolve, mosaic_h, mosaic_w, pair rows [P, 3], status [P])."""
+    from . import solve, synth
+    pair_idx, pair_dir = synth.grid_pairs(n_rows, n_cols)
+    _, out, status = register_streaming(fill_registration, n_rows, n_cols, tile_h, tile_w, pair_idx, pair_dir,
+                                        edge_width=edge_width, rows_per_band=rows_per_band,
+                                        flatfield=registration_flatfield, subpixel=subpixel)
+    out_np, st_np = out.cpu().numpy(), status.cpu().numpy()
+    row, col = np.repeat(np.arange(n_rows), n_cols), np.tile(np.arange(n_cols), n_rows)
+    pos = solve.solve_positions(solve.grid_from_pairs(row, col, pair_idx, pair_dir, out_np, st_np), tile_h, tile_w,
+                                pou, ncc_threshold)
+    grid_yx = np.stack([pos.y_pos, pos.x_pos], axis=1).astype(np.int32)
+    mosaic_h, mosaic_w = int(grid_yx[:, 0].max()) + tile_h, int(grid_yx[:, 1].max()) + tile_w
+    yx = grid_yx[np.asarray(tile_grid_index, dtype=np.int64)]
+    fuse_streaming(fill_tiles, drain, yx, tile_plane, n_planes, tile_h, tile_w, mosaic_h, mosaic_w, band_rows=band_rows,
+                   flatfields=flatfields, tile_ff=tile_ff, mode=mode)
+    return pos, mosaic_h, mosaic_w, out_np, st_np

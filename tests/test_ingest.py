@@ -91,3 +91,37 @@ def test_streamed_fusion_equals_the_one_shot_mosaic(mode, band_rows):
     assert seen == [(r, min(mh, r + band_rows)) for r in range(0, mh, band_rows)]
     assert np.array_equal(got, want)
     assert sorted(filled) == list(range(len(tiles)))      # every tile decoded and sent once, straddling or not
+
+
+@pytest.mark.gpu
+def test_host_to_host_stitch_reassembles_the_scenes():
+    """Two channels cut from two scenes at the same jittered positions; channel 0 registers.  The
+    streamed path must hand back mosaics whose covered pixels are the scenes'."""
+    rows, cols, t, jitter = 3, 4, 256, 3
+    g0 = synth.make_grid(61, rows, cols, t, t, overlap=0.125, jitter=jitter)
+    sh, sw = (rows - 1) * g0.pitch_y + t + 2 * jitter, (cols - 1) * g0.pitch_x + t + 2 * jitter
+    scenes = [synth.make_scene(61, sh, sw), synth.make_scene(62, sh, sw)]
+    tiles = np.stack([sc[y:y + t, x:x + t] for sc in scenes for y, x in g0.true_yx])
+    assert np.array_equal(tiles[:rows * cols], g0.tiles)
+    n = rows * cols
+    plane = np.repeat(np.arange(2), n).astype(np.int32)
+    grid_index = np.tile(np.arange(n), 2)
+    bands = {}
+
+    def drain(r0, r1, src):
+        bands[r0] = src.copy()
+
+    pos, mh, mw, out, status = ingest.stitch_streaming(
+        ingest.fill_from_array(g0.tiles), lambda idx, dst: np.copyto(dst, tiles[idx]), drain, rows, cols, t, t, 2, plane,
+        grid_index, edge_width=32, band_rows=200)
+    assert (status == 0).all() and np.array_equal(out[:, 1:].astype(np.int64), g0.expected_shift)
+    mosaic = np.concatenate([bands[r] for r in sorted(bands)], axis=1)
+    assert mosaic.shape == (2, mh, mw)
+    y0, x0 = g0.true_yx.min(axis=0)
+    covered = np.zeros((mh, mw), dtype=bool)
+    for y, x in zip(pos.y_pos, pos.x_pos):
+        covered[y:y + t, x:x + t] = True
+    for c in range(2):
+        want = scenes[c][y0:y0 + mh, x0:x0 + mw]
+        assert np.array_equal(mosaic[c][covered], want[covered])
+        assert (mosaic[c][~covered] == 0).all()
