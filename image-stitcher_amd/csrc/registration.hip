@@ -112,8 +112,10 @@ constexpr int kSlab = 8;
 __host__ __device__ __forceinline__ int64_t slab_pitch(int S) { return (int64_t)(S + (S & 1)) * kSlab + kSlab; }
 __host__ __device__ __forceinline__ int64_t slab_pair_elems(int S, int L) { return slab_pitch(S) * (L / kSlab); }
 
+// (bitwise operators on purpose, here and in first_better: short-circuit ones become a chain of
+// divergent branches around every comparison, several times the cost of the comparisons)
 __device__ __forceinline__ bool peak_better(double v, int k, double bv, int bk) {
-  return (v > bv) || (v == bv && k > bk);
+  return (v > bv) | ((v == bv) & (k > bk));
 }
 
 // ---- wave-wide reductions ---------------------------------------------------
@@ -203,7 +205,7 @@ __device__ __forceinline__ Peak wave_best_peak(Peak mine, Better better) {
 // Among equal values the SMALLEST key wins (the first occurrence in row-major order, as
 // numpy.argmax reports).
 __device__ __forceinline__ bool first_better(double v, int k, double bv, int bk) {
-  return (v > bv) || (v == bv && k >= 0 && (bk < 0 || k < bk));
+  return (v > bv) | ((v == bv) & (k >= 0) & ((bk < 0) | (k < bk)));
 }
 
 // Block-wide argmax of (val, key) carrying loc; result valid in every thread.
@@ -864,14 +866,16 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
     T v1 = neg_inf, v2 = neg_inf;
     int k1 = -1, k2 = -1;
     Peak ba{-INFINITY, -1, -1};  // largest magnitude, first in row-major order (subpixel stage only)
-    auto offer = [&](T v, int key) {
-      const bool gt1 = v > v1 || (v == v1 && key > k1);
-      const bool gt2 = v > v2 || (v == v2 && key > k2);
+    // branch-free: one pass of compares and selects per value (`have` false: the value does not exist)
+    auto offer = [&](T v, int key, bool have) {
+      const bool gt1 = have & ((v > v1) | ((v == v1) & (key > k1)));
+      const bool gt2 = have & ((v > v2) | ((v == v2) & (key > k2)));
       v2 = gt1 ? v1 : (gt2 ? v : v2);
       k2 = gt1 ? k1 : (gt2 ? key : k2);
       v1 = gt1 ? v : v1;
       k1 = gt1 ? key : k1;
     };
+    const bool want_abs = partial_abs != nullptr;
     for (int e = tid; e < NF * L; e += kThreads) {
       const int f = e >> lL, l = e & (L - 1);
       const cx<T> v = buf[addr(f, l)];
@@ -879,14 +883,19 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       const int key0 = d.transposed ? l * S + s : s * L + l;
       const int key1 = d.transposed ? key0 + 1 : key0 + L;
       const bool have0 = s < S, have1 = s + 1 < S;  // an odd S leaves the last transform half empty
-      if (have0) offer(v.x * cmp_scale, key0);
-      if (have1) offer(v.y * cmp_scale, key1);
-      if (partial_abs != nullptr) {
+      offer(v.x * cmp_scale, key0, have0);
+      offer(v.y * cmp_scale, key1, have1);
+      if (want_abs) {
         const double a0v = fabs((double)v.x * scale), a1v = fabs((double)v.y * scale);
-        if (have0 && first_better(a0v, key0, ba.val, ba.key)) ba = Peak{a0v, key0, 0};
-        if (have1 && first_better(a1v, key1, ba.val, ba.key)) ba = Peak{a1v, key1, 0};
+        const bool t0 = have0 & first_better(a0v, key0, ba.val, ba.key);
+        ba.val = t0 ? a0v : ba.val;
+        ba.key = t0 ? key0 : ba.key;
+        const bool t1 = have1 & first_better(a1v, key1, ba.val, ba.key);
+        ba.val = t1 ? a1v : ba.val;
+        ba.key = t1 ? key1 : ba.key;
       }
     }
+    ba.loc = ba.key >= 0 ? 0 : -1;
     Peak b1{k1 >= 0 ? (double)v1 * out_scale : -INFINITY, k1, k1}, b2{k2 >= 0 ? (double)v2 * out_scale : -INFINITY, k2, k2};
     if (partial_abs != nullptr) {
       const Peak best = block_argmax_first(ba, red);
