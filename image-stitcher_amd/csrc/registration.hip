@@ -3002,6 +3002,11 @@ extern "C" int mistitch_debug_stamps(unsigned long long* host_out /*[3][4096][8]
 }
 #endif
 
+static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
+                               int64_t tile_pitch, const void* ff, int ff_type, const int32_t* pair_idx,
+                               const uint8_t* pair_dir, int n_pairs, int edge_width, unsigned flags, double* out,
+                               int8_t* status);
+
 extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int edge_width,
                                              int max_pairs, unsigned flags) {
   MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
@@ -3022,7 +3027,40 @@ extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int 
   // slots large enough for either direction, as a call with a flatfield stages both
   const int64_t slot_elems = 2 * std::max((int64_t)w_left * tile_h, (int64_t)w_top * tile_w);
   const int stage_slots = stage_all_pairs(ctx, max_pairs, chunk, slot_elems) ? max_pairs : chunk;
-  return reserve_registration(ctx, max_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws);
+  if ((rc = reserve_registration(ctx, max_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws))) return rc;
+  // Whatever else a first call sets up (tables of the subpixel stage, kernels that need their LDS limit
+  // raised) is set up by making that call: max_pairs pairs of two blank tiles, left and top alternating.
+  // Blank tiles are featureless, so the kernels leave early, but every launch of a real call is made.
+  const size_t tile_elems = (size_t)tile_h * tile_w;
+  DevBuf scratch;
+  const size_t b_tiles = (2 * tile_elems * sizeof(uint16_t) + 255) / 256 * 256;
+  const size_t b_idx = ((size_t)max_pairs * 2 * sizeof(int32_t) + 255) / 256 * 256;
+  const size_t b_dir = ((size_t)max_pairs + 255) / 256 * 256;
+  const size_t b_out = ((size_t)max_pairs * 3 * sizeof(double) + 255) / 256 * 256;
+  if ((rc = scratch.reserve(b_tiles + b_idx + b_dir + b_out + (size_t)max_pairs + 256))) return rc;
+  char* base = reinterpret_cast<char*>(scratch.ptr);
+  std::vector<int32_t> h_idx((size_t)max_pairs * 2);
+  std::vector<uint8_t> h_dir((size_t)max_pairs);
+  for (int i = 0; i < max_pairs; ++i) {
+    h_idx[2 * i] = 0;
+    h_idx[2 * i + 1] = 1;
+    h_dir[i] = (uint8_t)(i & 1);
+  }
+  rc = MISTITCH_OK;
+  if (hipMemset(base, 0, b_tiles) != hipSuccess ||
+      hipMemcpy(base + b_tiles, h_idx.data(), h_idx.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(base + b_tiles + b_idx, h_dir.data(), h_dir.size(), hipMemcpyHostToDevice) != hipSuccess)
+    rc = set_error(MISTITCH_ERR_HIP, "could not set up the sizing call");
+  if (rc == MISTITCH_OK)
+    rc = register_pairs_impl(ctx, reinterpret_cast<const uint16_t*>(base), 2, tile_h, tile_w, (int64_t)tile_elems, nullptr,
+                             MISTITCH_FF_NONE, reinterpret_cast<const int32_t*>(base + b_tiles),
+                             reinterpret_cast<const uint8_t*>(base + b_tiles + b_idx), max_pairs, edge_width, flags,
+                             reinterpret_cast<double*>(base + b_tiles + b_idx + b_dir),
+                             reinterpret_cast<int8_t*>(base + b_tiles + b_idx + b_dir + b_out));
+  if (rc == MISTITCH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+    rc = set_error(MISTITCH_ERR_HIP, "the sizing call failed");
+  scratch.release();
+  return rc;
 }
 
 // Body of mistitch_register_pairs / mistitch_register_pairs_flatfield (ff = NULL: tiles are used as they are).

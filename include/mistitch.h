@@ -78,7 +78,9 @@ int mistitch_set_pair_chunk(mistitch_ctx* ctx, int pairs_per_pass);
 int mistitch_set_staging_limit(mistitch_ctx* ctx, int64_t bytes);
 
 /* Pre-size all workspaces so that later mistitch_register_pairs calls with
- * shapes up to these do not allocate. */
+ * shapes up to these do not allocate, copy tables or change kernel attributes (and can
+ * therefore be captured into a HIP graph): sizes the buffers, then makes one registration
+ * call of `max_pairs` pairs on two blank tiles with `flags` and waits for it. */
 int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int edge_width,
                                   int max_pairs, unsigned flags);
 

@@ -50,3 +50,30 @@ def test_step_replayed_from_a_graph_equals_the_eager_step():
         torch.cuda.synchronize()
         assert torch.equal(out, want_out) and torch.equal(status, want_status) and torch.equal(mosaic, want_mosaic)
     assert np.array_equal(np.round(want_out.cpu().numpy()[:, 1:]).astype(np.int64), g.expected_shift)
+
+
+def test_registration_captured_right_after_reserve():
+    """mistitch_reserve_registration alone (no warm-up call) must leave nothing to allocate."""
+    import torch
+    from image_stitcher_amd import _lib, registration
+    from image_stitcher_amd._lib import check, lib
+    dev = torch.device("cuda", 0)
+    g = synth.make_grid(8, 3, 5, 256, 192, overlap=0.125, jitter=3)
+    tiles = registration.to_device_u16(g.tiles)
+    s = torch.cuda.Stream(dev)
+    ctx = _lib.Context(0, s.cuda_stream, pair_chunk=6)     # several passes
+    n = len(g.pair_idx)
+    flags = _lib.FFT_F64 | _lib.REG_SUBPIXEL
+    check(lib.mistitch_reserve_registration(ctx.handle, 256, 192, 32, n, flags))
+    out = torch.empty((n, 3), dtype=torch.float64, device=dev)
+    status = torch.empty((n,), dtype=torch.int8, device=dev)
+    d_idx = torch.as_tensor(g.pair_idx, dtype=torch.int32, device=dev)
+    d_dir = torch.as_tensor(g.pair_dir, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        registration.register_pairs(tiles, d_idx, d_dir, 32, ctx=ctx, out=out, status=status, subpixel=True)
+    graph.replay()
+    torch.cuda.synchronize()
+    want, want_st = registration.register_pairs(tiles, d_idx, d_dir, 32, subpixel=True)
+    assert torch.equal(status, want_st) and torch.equal(out, want)
