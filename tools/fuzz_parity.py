@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Randomised differential check of the device path against the CPU oracle: registration of random
+grids (any tile size, edge width, jitter, featureless tiles) and fusion of random tile layouts
+(any overlap depth, planes, flatfields, tiles cut by the mosaic edge).  Prints a progress line
+per batch and the first disagreement in full."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def fuzz_registration(rng, reg, oreg, synth):
+    rows, cols = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+    if rows * cols == 1:
+        cols = 2
+    if rng.random() < 0.5:
+        th, tw = (int(2 ** rng.integers(5, 9)) for _ in range(2))
+    else:
+        th, tw = int(rng.integers(24, 300)), int(rng.integers(24, 300))
+    overlap = float(rng.uniform(0.08, 0.3))
+    jitter = int(rng.integers(0, 4))
+    edge = int(rng.choice([8, 16, 32, 64, int(rng.integers(3, 80))]))
+    g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, th, tw, overlap=overlap, jitter=jitter)
+    blank = rng.random() < 0.3
+    if blank:
+        g.tiles[int(rng.integers(rows * cols))] = int(rng.integers(0, 65536))
+    # (not a flatfield over a blank tile: constant / smooth is no longer featureless, and its spectrum is zero to
+    # rounding in most bins, where the normalised cross-power spectrum is rounding noise in any implementation)
+    flat = synth.make_flatfield(th, tw, amplitude=float(rng.uniform(0, 0.5))) if rng.random() < 0.4 and not blank else None
+    tiles_for_oracle = g.tiles
+    if flat is not None:
+        from oracle import fusion as ofu
+        tiles_for_oracle = np.stack([ofu.apply_flatfield(t, flat) for t in g.tiles])
+    out, st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, flatfield=flat)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    exp, exp_st = oreg.register_pairs(tiles_for_oracle, g.pair_idx, g.pair_dir, edge, polish=False)
+    ok_rows = exp_st == 0
+    good = (np.array_equal(st == 1, exp_st == 1) and np.array_equal(out[ok_rows, 1:], exp[ok_rows, 1:])
+            and np.allclose(out[ok_rows, 0], exp[ok_rows, 0], rtol=0, atol=1e-9, equal_nan=True))
+    desc = dict(kind="registration", rows=rows, cols=cols, tile=(th, tw), overlap=overlap, jitter=jitter, edge=edge,
+                flatfield=flat is not None)
+    return good, desc, (out, st, exp, exp_st)
+
+
+def fuzz_fusion(rng, fu, ofu, synth):
+    th, tw = int(rng.integers(5, 90)), int(rng.integers(5, 140))
+    n = int(rng.integers(1, 40))
+    planes = int(rng.integers(1, 4))
+    mh, mw = int(rng.integers(th, 4 * th + 40)), int(rng.integers(tw, 4 * tw + 300))
+    tiles = rng.integers(0, 65536, size=(n, th, tw)).astype(np.uint16)
+    yx = np.stack([rng.integers(0, max(1, mh - th // 2), size=n), rng.integers(0, max(1, mw - tw // 2), size=n)], axis=1)
+    if rng.random() < 0.5:      # a regular-ish grid instead of a random scatter
+        cols = max(1, int(np.sqrt(n)))
+        py, px = max(1, int(th * rng.uniform(0.5, 1.0))), max(1, int(tw * rng.uniform(0.5, 1.0)))
+        yx = np.array([[(i // cols) * py + rng.integers(0, 3), (i % cols) * px + rng.integers(0, 3)] for i in range(n)])
+    # every tile at least partly inside the mosaic (the reference's clip cannot place one that is not)
+    yx = np.minimum(yx, [mh - 1, mw - 1]).astype(np.int32)
+    plane = rng.integers(0, planes, size=n).astype(np.int32)
+    with_ff = rng.random() < 0.6
+    dt = np.float32 if rng.random() < 0.7 else np.float64
+    ffs = np.stack([synth.make_flatfield(th, tw, dtype=dt, amplitude=float(rng.uniform(0, 0.6))) for _ in range(planes)]) \
+        if with_ff else None
+    tile_ff = plane.copy() if with_ff else None
+    if with_ff and rng.random() < 0.3:
+        tile_ff[rng.integers(0, n)] = -1
+    mode = "overwrite" if rng.random() < 0.5 else "feather"
+    got = fu.fuse_tiles(tiles, yx, plane, planes, mh, mw, flatfields=ffs, tile_ff=tile_ff, mode=mode).cpu().numpy()
+    oracle = ofu.fuse_overwrite if mode == "overwrite" else ofu.fuse_feather
+    want = oracle(tiles, yx, plane, planes, mh, mw, flatfields=ffs, tile_ff=tile_ff)
+    desc = dict(kind="fusion", tile=(th, tw), n=n, planes=planes, mosaic=(mh, mw), mode=mode, ff=str(dt.__name__) if with_ff else None)
+    return bool(np.array_equal(got, want)), desc, (got, want, yx, plane)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+    import torch
+    assert torch.cuda.is_available()
+    from image_stitcher_amd import fusion as fu, registration as reg, synth
+    from oracle import fusion as ofu, registration as oreg
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    counts = {"registration": 0, "fusion": 0}
+    last = t0
+    while time.time() - t0 < args.seconds:
+        kind = "registration" if rng.random() < 0.5 else "fusion"
+        good, desc, data = (fuzz_registration(rng, reg, oreg, synth) if kind == "registration"
+                            else fuzz_fusion(rng, fu, ofu, synth))
+        counts[kind] += 1
+        if not good:
+            print("DISAGREEMENT", desc, flush=True)
+            if kind == "registration":
+                out, st, exp, exp_st = data
+                print(np.concatenate([out, st[:, None], exp, exp_st[:, None]], axis=1))
+            else:
+                got, want, yx, plane = data
+                bad = np.argwhere(got != want)
+                print(len(bad), "pixels differ; first:", bad[:5].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
+                print(yx.tolist(), plane.tolist())
+            return 1
+        if time.time() - last > 20:
+            print(f"{time.time() - t0:.0f} s: {counts}", flush=True)
+            last = time.time()
+    print("FUZZ OK", counts, flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
