@@ -75,27 +75,94 @@ def fuzz_fusion(rng, fu, ofu, synth):
     return bool(np.array_equal(got, want)), desc, (got, want, yx, plane)
 
 
+def fuzz_subpixel(rng, reg, osp, synth):
+    """Registration with the upsampled-DFT candidate; compared where the pair really overlaps (oracle NCC > 0.5):
+    in pure noise the upsampled maximum sits on a plateau of near-ties."""
+    rows, cols = (1, 2) if rng.random() < 0.5 else (2, 1)
+    th, tw = (int(2 ** rng.integers(6, 9)) for _ in range(2)) if rng.random() < 0.5 else \
+        (int(rng.integers(48, 260)), int(rng.integers(48, 260)))
+    overlap, jitter = float(rng.uniform(0.15, 0.3)), int(rng.integers(0, 4))
+    edge = int(rng.choice([16, 32, 64, int(rng.integers(12, 70))]))
+    g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, th, tw, overlap=overlap, jitter=jitter)
+    uf = int(rng.choice([100, 100, 10, 37]))
+    out, st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, subpixel=True, upsample_factor=uf)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    exp, exp_st, _ = osp.register_pairs_subpixel(g.tiles, g.pair_idx, g.pair_dir, edge, uf)
+    sure = (exp_st == 0) & (exp[:, 0] > 0.5)
+    good = bool(np.array_equal(st == 1, exp_st == 1) and
+                (not sure.any() or (np.abs(out[sure, 1:] - exp[sure, 1:]).max() <= 1.0 / uf + 1e-9
+                                    and np.abs(out[sure, 0] - exp[sure, 0]).max() <= 1e-9)))
+    return good, dict(kind="subpixel", grid=(rows, cols), tile=(th, tw), overlap=overlap, jitter=jitter, edge=edge, uf=uf), \
+        (out, st, exp, exp_st)
+
+
+def fuzz_refine(rng, reg, oref, synth):
+    rows, cols = int(rng.integers(1, 3)), int(rng.integers(2, 4))
+    th, tw = int(rng.integers(40, 200)), int(rng.integers(40, 200))
+    overlap, jitter = float(rng.uniform(0.12, 0.3)), int(rng.integers(0, 4))
+    edge = int(rng.integers(8, 48))
+    g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, th, tw, overlap=overlap, jitter=jitter)
+    start = g.expected_shift + rng.integers(-3, 4, size=g.expected_shift.shape)
+    if rng.random() < 0.2:
+        start[0] = (5 * th, 3)      # outside its limits: the start is kept
+    r = float(rng.choice([0, 1, 2.5, 6, 20]))
+    out, _ = reg.refine_pairs(g.tiles, g.pair_idx, g.pair_dir, start, r, edge)
+    out = out.cpu().numpy()
+    exp = oref.refine_pairs(g.tiles, g.pair_idx, g.pair_dir, start, r, edge)
+    good = bool(np.array_equal(out[:, 1:], exp[:, 1:]) and np.allclose(out[:, 0], exp[:, 0], rtol=0, atol=1e-9, equal_nan=True))
+    return good, dict(kind="refine", grid=(rows, cols), tile=(th, tw), edge=edge, r=r), (out, np.zeros(len(out)), exp, np.zeros(len(out)))
+
+
+def fuzz_fusion_wide(rng, fu, ofu, synth):
+    """Mosaics several blocks wide and tall (a block is 32 rows by 2048 pixels), few tall tiles."""
+    th, tw = int(rng.integers(8, 120)), int(rng.integers(200, 1700))
+    n = int(rng.integers(1, 14))
+    planes = int(rng.integers(1, 3))
+    mh, mw = int(rng.integers(th, 3 * th + 60)), int(rng.integers(max(tw, 2049), 7000))
+    tiles = rng.integers(0, 65536, size=(n, th, tw)).astype(np.uint16)
+    yx = np.stack([rng.integers(0, mh - th // 2, size=n), rng.integers(0, mw - tw // 2, size=n)], axis=1)
+    if rng.random() < 0.5:      # a row of overlapping tiles, as a grid row is
+        px = int(tw * rng.uniform(0.7, 0.98))
+        yx = np.array([[rng.integers(0, 6), i * px + rng.integers(0, 9)] for i in range(n)])
+    yx = np.minimum(yx, [mh - 1, mw - 1]).astype(np.int32)
+    plane = rng.integers(0, planes, size=n).astype(np.int32)
+    with_ff = rng.random() < 0.6
+    ffs = np.stack([synth.make_flatfield(th, tw, amplitude=float(rng.uniform(0, 0.6))) for _ in range(planes)]) if with_ff else None
+    mode = "overwrite" if rng.random() < 0.5 else "feather"
+    got = fu.fuse_tiles(tiles, yx, plane, planes, mh, mw, flatfields=ffs, tile_ff=plane if with_ff else None, mode=mode).cpu().numpy()
+    oracle = ofu.fuse_overwrite if mode == "overwrite" else ofu.fuse_feather
+    want = oracle(tiles, yx, plane, planes, mh, mw, flatfields=ffs, tile_ff=plane if with_ff else None)
+    return bool(np.array_equal(got, want)), dict(kind="fusion_wide", tile=(th, tw), n=n, planes=planes, mosaic=(mh, mw),
+                                                  mode=mode, ff=with_ff), (got, want, yx, plane)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", default="", help="comma-separated kinds to run (default: all)")
     args = ap.parse_args()
     import torch
     assert torch.cuda.is_available()
     from image_stitcher_amd import fusion as fu, registration as reg, synth
-    from oracle import fusion as ofu, registration as oreg
+    from oracle import fusion as ofu, refine as oref, registration as oreg, subpixel as osp
     rng = np.random.default_rng(args.seed)
     t0 = time.time()
-    counts = {"registration": 0, "fusion": 0}
+    runners = {"registration": lambda: fuzz_registration(rng, reg, oreg, synth),
+               "fusion": lambda: fuzz_fusion(rng, fu, ofu, synth),
+               "subpixel": lambda: fuzz_subpixel(rng, reg, osp, synth),
+               "refine": lambda: fuzz_refine(rng, reg, oref, synth),
+               "fusion_wide": lambda: fuzz_fusion_wide(rng, fu, ofu, synth)}
+    kinds = [k for k in runners if not args.only or k in args.only.split(",")]
+    counts = {k: 0 for k in kinds}
     last = t0
     while time.time() - t0 < args.seconds:
-        kind = "registration" if rng.random() < 0.5 else "fusion"
-        good, desc, data = (fuzz_registration(rng, reg, oreg, synth) if kind == "registration"
-                            else fuzz_fusion(rng, fu, ofu, synth))
+        kind = kinds[int(rng.integers(len(kinds)))]
+        good, desc, data = runners[kind]()
         counts[kind] += 1
         if not good:
             print("DISAGREEMENT", desc, flush=True)
-            if kind == "registration":
+            if kind in ("registration", "subpixel", "refine"):
                 out, st, exp, exp_st = data
                 print(np.concatenate([out, st[:, None], exp, exp_st[:, None]], axis=1))
             else:
