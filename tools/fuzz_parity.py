@@ -113,6 +113,67 @@ def fuzz_refine(rng, reg, oref, synth):
     return good, dict(kind="refine", grid=(rows, cols), tile=(th, tw), edge=edge, r=r), (out, np.zeros(len(out)), exp, np.zeros(len(out)))
 
 
+def fuzz_registration_big(rng, reg, oreg, synth):
+    """Production-sized strips: long sides 256-2048 (radix plans of every length), edge widths up to 256."""
+    rows, cols = (1, 2) if rng.random() < 0.5 else (2, 1)
+    pick = (lambda: int(rng.choice([256, 512, 1024, 2048, int(rng.integers(300, 1100))])))
+    th, tw = pick(), pick()
+    edge = int(rng.choice([64, 128, 256, 195, int(rng.integers(20, 256))]))
+    g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, th, tw, overlap=float(rng.uniform(0.08, 0.2)),
+                        jitter=int(rng.integers(0, 6)))
+    fft = "f64" if rng.random() < 0.7 else "f32"
+    out, st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, fft=fft)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    exp, exp_st = oreg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, polish=False)
+    good = bool(np.array_equal(st, exp_st) and np.array_equal(out[:, 1:], exp[:, 1:])
+                and np.allclose(out[:, 0], exp[:, 0], rtol=0, atol=1e-9))
+    return good, dict(kind="registration_big", grid=(rows, cols), tile=(th, tw), edge=edge, fft=fft), (out, st, exp, exp_st)
+
+
+def fuzz_apis(rng, reg, fu, oreg, ofu, synth):
+    """The one-call mirrors: ncc, pcm_topk, flatfield, z projection, pyramid."""
+    which = int(rng.integers(5))
+    if which == 0:
+        h, w = int(rng.integers(1, 400)), int(rng.integers(1, 400))
+        a = rng.integers(0, 65536, size=(h, w)).astype(np.uint16)
+        b = (a // 2 + rng.integers(0, 30000, size=a.shape)).astype(np.uint16) if rng.random() < 0.7 else np.full_like(a, 7)
+        got, want = reg.ncc(a, b), oreg.ncc(a, b)
+        good = (got == want) or abs(got - want) < 1e-9
+        return bool(good), dict(kind="apis", api="ncc", shape=(h, w)), (np.array([[got, 0, 0]]), np.zeros(1), np.array([[want, 0, 0]]), np.zeros(1))
+    if which == 1:
+        h, w = int(rng.integers(3, 200)), int(rng.integers(8, 300))
+        big = synth.make_scene(int(rng.integers(1 << 30)), h + 16, w + 16)
+        dy, dx = int(rng.integers(-5, 6)), int(rng.integers(-5, 6))
+        dy = 1 if dy == dx == 0 else dy     # identical strips: a delta, the other 'peaks' are rounding noise at 1e-16
+        a, b = np.ascontiguousarray(big[8:8 + h, 8:8 + w]), np.ascontiguousarray(big[8 + dy:8 + dy + h, 8 + dx:8 + dx + w])
+        k = int(rng.integers(1, 5))
+        r, c, v = reg.pcm_topk(a, b, k=k)
+        er, ec, ev = oreg.multi_peak_max(oreg.pcm(a, b))
+        good = np.array_equal(r, er[:k]) and np.array_equal(c, ec[:k]) and np.allclose(v, ev[:k], rtol=0, atol=1e-10)
+        pack = (lambda rr, cc, vv: np.stack([vv, rr, cc], axis=1).astype(np.float64))
+        return bool(good), dict(kind="apis", api="pcm_topk", shape=(h, w), k=k), (pack(r, c, v), np.zeros(k), pack(er[:k], ec[:k], ev[:k]), np.zeros(k))
+    if which == 2:
+        h, w = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        img = rng.integers(0, 65536, size=(h, w)).astype(np.uint16)
+        dt = np.float32 if rng.random() < 0.6 else np.float64
+        ff = synth.make_flatfield(h, w, dtype=dt, amplitude=float(rng.uniform(0, 0.9))) if min(h, w) > 1 else np.ones((h, w), dtype=dt)
+        got, want = fu.apply_flatfield_to_image(img, ff), ofu.apply_flatfield(img, ff)
+        return bool(np.array_equal(got, want)), dict(kind="apis", api="flatfield", shape=(h, w), dtype=dt.__name__), \
+            (got[None], want[None], np.zeros((1, 2)), np.zeros(1))
+    if which == 3:
+        z, h, w = int(rng.integers(1, 7)), int(rng.integers(1, 200)), int(rng.integers(1, 300))
+        st = rng.integers(0, 65536, size=(z, h, w)).astype(np.uint16)
+        got, want = fu.compute_mip(list(st)), ofu.compute_mip(list(st))
+        return bool(np.array_equal(got, want)), dict(kind="apis", api="mip", shape=(z, h, w)), (got[None], want[None], np.zeros((1, 2)), np.zeros(1))
+    planes, h, w = int(rng.integers(1, 4)), int(rng.integers(2, 400)), int(rng.integers(2, 600))
+    img = rng.integers(0, 65536, size=(planes, h, w)).astype(np.uint16)
+    levels = int(rng.integers(1, 7))
+    got, want = fu.generate_pyramid(img, levels), ofu.generate_pyramid(img, levels)
+    good = len(got) == len(want) and all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(got, want))
+    return bool(good), dict(kind="apis", api="pyramid", shape=(planes, h, w), levels=levels), \
+        (np.zeros((1, 1, 1)), np.ones((1, 1, 1)), np.zeros((1, 2)), np.zeros(1))
+
+
 def fuzz_fusion_wide(rng, fu, ofu, synth):
     """Mosaics several blocks wide and tall (a block is 32 rows by 2048 pixels), few tall tiles."""
     th, tw = int(rng.integers(8, 120)), int(rng.integers(200, 1700))
@@ -152,7 +213,9 @@ def main():
                "fusion": lambda: fuzz_fusion(rng, fu, ofu, synth),
                "subpixel": lambda: fuzz_subpixel(rng, reg, osp, synth),
                "refine": lambda: fuzz_refine(rng, reg, oref, synth),
-               "fusion_wide": lambda: fuzz_fusion_wide(rng, fu, ofu, synth)}
+               "fusion_wide": lambda: fuzz_fusion_wide(rng, fu, ofu, synth),
+               "registration_big": lambda: fuzz_registration_big(rng, reg, oreg, synth),
+               "apis": lambda: fuzz_apis(rng, reg, fu, oreg, ofu, synth)}
     kinds = [k for k in runners if not args.only or k in args.only.split(",")]
     counts = {k: 0 for k in kinds}
     last = t0
@@ -162,7 +225,7 @@ def main():
         counts[kind] += 1
         if not good:
             print("DISAGREEMENT", desc, flush=True)
-            if kind in ("registration", "subpixel", "refine"):
+            if kind in ("registration", "subpixel", "refine", "registration_big") or desc.get("api") in ("ncc", "pcm_topk"):
                 out, st, exp, exp_st = data
                 print(np.concatenate([out, st[:, None], exp, exp_st[:, None]], axis=1))
             else:
