@@ -174,6 +174,62 @@ def fuzz_apis(rng, reg, fu, oreg, ofu, synth):
         (np.zeros((1, 1, 1)), np.ones((1, 1, 1)), np.zeros((1, 2)), np.zeros(1))
 
 
+_CTX = {}
+
+
+def fuzz_pipeline(rng, reg, fu, synth):
+    """Device against device: passes smaller than the call (staged at once or pass by pass), the streamed upload +
+    registration and the band-streamed fusion must reproduce the single resident call bit for bit."""
+    import torch
+    from image_stitcher_amd import _lib, ingest
+    if not _CTX:
+        for chunk in (1, 3, 7):
+            for limit in (None, 0):
+                c = _lib.Context(0, torch.cuda.current_stream().cuda_stream, pair_chunk=chunk)
+                if limit is not None:
+                    c.set_staging_limit(limit)
+                _CTX[(chunk, limit)] = c
+    rows, cols = int(rng.integers(2, 5)), int(rng.integers(2, 5))
+    th, tw = int(rng.integers(32, 200)), int(rng.integers(32, 200))
+    edge = int(rng.integers(6, 40))
+    g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, th, tw, overlap=float(rng.uniform(0.1, 0.3)),
+                        jitter=int(rng.integers(0, 4)))
+    flat = synth.make_flatfield(th, tw, amplitude=float(rng.uniform(0, 0.4))) if rng.random() < 0.5 else None
+    sub = rng.random() < 0.3
+    want, want_st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, flatfield=flat, subpixel=sub)
+    ctx = _CTX[(int(rng.choice([1, 3, 7])), None if rng.random() < 0.5 else 0)]
+    got, got_st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, flatfield=flat, subpixel=sub, ctx=ctx)
+    same = (lambda a, b: torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)))   # featureless rows are NaN
+    ok_passes = bool(torch.equal(want_st, got_st) and same(want, got))
+    if not ok_passes:
+        print("passes differ:", torch.cat([want, got, want_st[:, None].double(), got_st[:, None].double()], dim=1).cpu().numpy(), flush=True)
+    good = ok_passes
+    _, s_out, s_st = ingest.register_streaming(ingest.fill_from_array(g.tiles), rows, cols, th, tw, g.pair_idx, g.pair_dir,
+                                               edge_width=edge, rows_per_band=int(rng.integers(1, rows + 1)), flatfield=flat,
+                                               subpixel=sub)
+    ok_stream = bool(torch.equal(want_st, s_st) and same(want, s_out))
+    if not ok_stream:
+        print("streamed differs:", torch.cat([want, s_out, want_st[:, None].double(), s_st[:, None].double()], dim=1).cpu().numpy(), flush=True)
+    good = good and ok_stream
+    yx = (g.true_yx - g.true_yx.min(axis=0)).astype(np.int32)
+    mh, mw = int(yx[:, 0].max()) + th, int(yx[:, 1].max()) + tw
+    plane = np.zeros(rows * cols, dtype=np.int32)
+    mode = "overwrite" if rng.random() < 0.5 else "feather"
+    ffs = None if flat is None else flat[None]
+    one = fu.fuse_tiles(g.tiles, yx, plane, 1, mh, mw, flatfields=ffs, tile_ff=None if flat is None else plane, mode=mode).cpu().numpy()
+    banded = np.full_like(one, 0xABCD)
+
+    def drain(r0, r1, src):
+        banded[:, r0:r1] = src
+
+    ingest.fuse_streaming(lambda idx, dst: np.copyto(dst, g.tiles[idx]), drain, yx, plane, 1, th, tw, mh, mw,
+                          band_rows=int(rng.integers(8, mh + 10)), flatfields=ffs, tile_ff=None if flat is None else plane,
+                          mode=mode)
+    good = good and np.array_equal(one, banded)
+    return bool(good), dict(kind="pipeline", grid=(rows, cols), tile=(th, tw), edge=edge, flat=flat is not None, sub=sub,
+                            mode=mode), (one, banded, yx, plane)
+
+
 def fuzz_fusion_wide(rng, fu, ofu, synth):
     """Mosaics several blocks wide and tall (a block is 32 rows by 2048 pixels), few tall tiles."""
     th, tw = int(rng.integers(8, 120)), int(rng.integers(200, 1700))
@@ -215,7 +271,8 @@ def main():
                "refine": lambda: fuzz_refine(rng, reg, oref, synth),
                "fusion_wide": lambda: fuzz_fusion_wide(rng, fu, ofu, synth),
                "registration_big": lambda: fuzz_registration_big(rng, reg, oreg, synth),
-               "apis": lambda: fuzz_apis(rng, reg, fu, oreg, ofu, synth)}
+               "apis": lambda: fuzz_apis(rng, reg, fu, oreg, ofu, synth),
+               "pipeline": lambda: fuzz_pipeline(rng, reg, fu, synth)}
     kinds = [k for k in runners if not args.only or k in args.only.split(",")]
     counts = {k: 0 for k in kinds}
     last = t0
@@ -231,7 +288,8 @@ def main():
             else:
                 got, want, yx, plane = data
                 bad = np.argwhere(got != want)
-                print(len(bad), "pixels differ; first:", bad[:5].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
+                if len(bad):
+                    print(len(bad), "pixels differ; first:", bad[:5].tolist(), got[tuple(bad[0])], want[tuple(bad[0])])
                 print(yx.tolist(), plane.tolist())
             return 1
         if time.time() - last > 20:
