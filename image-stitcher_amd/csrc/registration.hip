@@ -287,6 +287,9 @@ __global__ void k_setup_pairs(const uint16_t* tiles, int64_t tile_pitch, int H, 
     d.off_y = H - w_top;
     d.off_x = 0;
   }
+  // the reference's peak ranking refuses a correlation matrix with a side below 2
+  // (_validate_pcm_input, _translation_computation.py:444-477, called by multi_peak_max) and the pair fails like a featureless one
+  if (d.S < 2 || d.L < 2) st = MISTITCH_PAIR_FEATURELESS;
   desc[p] = d;
   status[p] = (int8_t)st;
 }

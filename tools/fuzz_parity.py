@@ -174,6 +174,61 @@ def fuzz_apis(rng, reg, fu, oreg, ofu, synth):
         (np.zeros((1, 1, 1)), np.ones((1, 1, 1)), np.zeros((1, 2)), np.zeros(1))
 
 
+STATS = {}
+
+
+def fuzz_registration_tiny(rng, reg, oreg, synth):
+    """Tiles of a few pixels, edge widths from 1: the smallest transforms, overlaps below the 25-pixel minimum."""
+    rows, cols = (1, 2) if rng.random() < 0.5 else (2, 1)
+    th, tw = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+    edge = int(rng.integers(1, 50))
+    g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, th, tw, overlap=float(rng.uniform(0.1, 0.5)),
+                        jitter=int(rng.integers(0, 2)))
+    try:
+        exp, exp_st = oreg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, polish=False)
+    except Exception as exc:      # a shape the oracle rejects must be rejected by the library too
+        try:
+            reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge)
+            return False, dict(kind="registration_tiny", tile=(th, tw), edge=edge, oracle_error=str(exc)[:60]), \
+                (np.zeros((1, 3)), np.zeros(1), np.zeros((1, 3)), np.zeros(1))
+        except Exception:
+            STATS["both_reject"] = STATS.get("both_reject", 0) + 1
+            return True, {}, None
+    try:
+        out, st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge)
+    except Exception as exc:
+        # strips too small for the transforms are an explicit error of the library, never a wrong answer
+        STATS["library_refuses"] = STATS.get("library_refuses", 0) + 1
+        return "unsupported" in str(exc).lower() or "side" in str(exc).lower(), \
+            dict(kind="registration_tiny", tile=(th, tw), edge=edge, error=str(exc)[:80]), \
+            (np.zeros((1, 3)), np.zeros(1), exp, exp_st)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    ok_rows = exp_st == 0
+    STATS["compared_ok_rows"] = STATS.get("compared_ok_rows", 0) + int(ok_rows.sum())
+    STATS["compared_failed_rows"] = STATS.get("compared_failed_rows", 0) + int((~ok_rows).sum())
+    good = (np.array_equal(st == 1, exp_st == 1) and np.array_equal(out[ok_rows, 1:], exp[ok_rows, 1:])
+            and np.allclose(out[ok_rows, 0], exp[ok_rows, 0], rtol=0, atol=1e-9, equal_nan=True))
+    return bool(good), dict(kind="registration_tiny", tile=(th, tw), edge=edge), (out, st, exp, exp_st)
+
+
+def fuzz_fusion_tiny(rng, fu, ofu, synth):
+    th, tw = int(rng.integers(1, 12)), int(rng.integers(1, 12))
+    n = int(rng.integers(1, 30))
+    planes = int(rng.integers(1, 3))
+    mh, mw = int(rng.integers(th, th + 30)), int(rng.integers(tw, tw + 40))
+    tiles = rng.integers(0, 65536, size=(n, th, tw)).astype(np.uint16)
+    yx = np.stack([rng.integers(0, mh, size=n), rng.integers(0, mw, size=n)], axis=1).astype(np.int32)
+    plane = rng.integers(0, planes, size=n).astype(np.int32)
+    with_ff = rng.random() < 0.5
+    ffs = (0.5 + rng.random((planes, th, tw))).astype(np.float32) if with_ff else None
+    mode = "overwrite" if rng.random() < 0.5 else "feather"
+    got = fu.fuse_tiles(tiles, yx, plane, planes, mh, mw, flatfields=ffs, tile_ff=plane if with_ff else None, mode=mode).cpu().numpy()
+    oracle = ofu.fuse_overwrite if mode == "overwrite" else ofu.fuse_feather
+    want = oracle(tiles, yx, plane, planes, mh, mw, flatfields=ffs, tile_ff=plane if with_ff else None)
+    return bool(np.array_equal(got, want)), dict(kind="fusion_tiny", tile=(th, tw), n=n, mosaic=(mh, mw), mode=mode, ff=with_ff), \
+        (got, want, yx, plane)
+
+
 _CTX = {}
 
 
@@ -272,7 +327,9 @@ def main():
                "fusion_wide": lambda: fuzz_fusion_wide(rng, fu, ofu, synth),
                "registration_big": lambda: fuzz_registration_big(rng, reg, oreg, synth),
                "apis": lambda: fuzz_apis(rng, reg, fu, oreg, ofu, synth),
-               "pipeline": lambda: fuzz_pipeline(rng, reg, fu, synth)}
+               "pipeline": lambda: fuzz_pipeline(rng, reg, fu, synth),
+               "registration_tiny": lambda: fuzz_registration_tiny(rng, reg, oreg, synth),
+               "fusion_tiny": lambda: fuzz_fusion_tiny(rng, fu, ofu, synth)}
     kinds = [k for k in runners if not args.only or k in args.only.split(",")]
     counts = {k: 0 for k in kinds}
     last = t0
@@ -282,7 +339,7 @@ def main():
         counts[kind] += 1
         if not good:
             print("DISAGREEMENT", desc, flush=True)
-            if kind in ("registration", "subpixel", "refine", "registration_big") or desc.get("api") in ("ncc", "pcm_topk"):
+            if kind in ("registration", "subpixel", "refine", "registration_big", "registration_tiny") or desc.get("api") in ("ncc", "pcm_topk"):
                 out, st, exp, exp_st = data
                 print(np.concatenate([out, st[:, None], exp, exp_st[:, None]], axis=1))
             else:
@@ -295,7 +352,7 @@ def main():
         if time.time() - last > 20:
             print(f"{time.time() - t0:.0f} s: {counts}", flush=True)
             last = time.time()
-    print("FUZZ OK", counts, flush=True)
+    print("FUZZ OK", counts, STATS if STATS else "", flush=True)
     return 0
 
 
