@@ -13,7 +13,8 @@ fz = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(fz)
 
 CASES = {"registration": 150, "fusion": 150, "subpixel": 80, "refine": 80, "fusion_wide": 60, "registration_big": 12,
-         "apis": 150, "pipeline": 60, "registration_tiny": 400, "fusion_tiny": 300}
+         "apis": 150, "pipeline": 60, "registration_tiny": 400, "fusion_tiny": 300,
+         "featureless": 300}
 
 
 @pytest.mark.parametrize("kind", sorted(CASES))
@@ -32,7 +33,8 @@ def test_random_inputs_agree_with_the_oracle(kind):
            "apis": lambda: fz.fuzz_apis(rng, reg, fu, oreg, ofu, synth),
            "pipeline": lambda: fz.fuzz_pipeline(rng, reg, fu, synth),
            "registration_tiny": lambda: fz.fuzz_registration_tiny(rng, reg, oreg, synth),
-           "fusion_tiny": lambda: fz.fuzz_fusion_tiny(rng, fu, ofu, synth)}[kind]
+           "fusion_tiny": lambda: fz.fuzz_fusion_tiny(rng, fu, ofu, synth),
+           "featureless": lambda: fz.fuzz_featureless(rng, reg, oreg, synth)}[kind]
     for i in range(CASES[kind]):
         good, desc, _ = run()
         assert good, (i, desc)

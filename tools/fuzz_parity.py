@@ -177,6 +177,25 @@ def fuzz_apis(rng, reg, fu, oreg, ofu, synth):
 STATS = {}
 
 
+def fuzz_featureless(rng, reg, oreg, synth):
+    """Strips whose sampled variance sits at the featureless threshold (2e3): the decision must be the oracle's."""
+    th, tw = int(rng.integers(32, 300)), int(rng.integers(32, 300))
+    edge = int(rng.integers(8, 80))
+    direction = int(rng.integers(2))
+    tex = synth.make_scene(int(rng.integers(1 << 30)), th, tw)
+    amp = float(rng.uniform(130.0, 180.0))      # uniform noise of this amplitude has variance amp^2 / 12: 1.4e3 .. 2.7e3
+    base = int(rng.integers(0, 60000))
+    dull = (base + amp * rng.random((th, tw))).astype(np.uint16)
+    tiles = np.stack([dull, tex] if rng.random() < 0.5 else [tex, dull])
+    out, st = reg.register_pairs(tiles, [[0, 1]], [direction], edge)
+    st = st.cpu().numpy()
+    exp, exp_st = oreg.register_pairs(tiles, [[0, 1]], [direction], edge, polish=False)
+    STATS["featureless_yes"] = STATS.get("featureless_yes", 0) + int(exp_st[0] == 1)
+    STATS["featureless_no"] = STATS.get("featureless_no", 0) + int(exp_st[0] == 0)
+    return bool((st[0] == 1) == (exp_st[0] == 1)), dict(kind="featureless", tile=(th, tw), edge=edge, amp=amp, dir=direction), \
+        (out.cpu().numpy(), st, exp, exp_st)
+
+
 def fuzz_registration_tiny(rng, reg, oreg, synth):
     """Tiles of a few pixels, edge widths from 1: the smallest transforms, overlaps below the 25-pixel minimum."""
     rows, cols = (1, 2) if rng.random() < 0.5 else (2, 1)
@@ -329,7 +348,8 @@ def main():
                "apis": lambda: fuzz_apis(rng, reg, fu, oreg, ofu, synth),
                "pipeline": lambda: fuzz_pipeline(rng, reg, fu, synth),
                "registration_tiny": lambda: fuzz_registration_tiny(rng, reg, oreg, synth),
-               "fusion_tiny": lambda: fuzz_fusion_tiny(rng, fu, ofu, synth)}
+               "fusion_tiny": lambda: fuzz_fusion_tiny(rng, fu, ofu, synth),
+               "featureless": lambda: fuzz_featureless(rng, reg, oreg, synth)}
     kinds = [k for k in runners if not args.only or k in args.only.split(",")]
     counts = {k: 0 for k in kinds}
     last = t0
@@ -339,7 +359,7 @@ def main():
         counts[kind] += 1
         if not good:
             print("DISAGREEMENT", desc, flush=True)
-            if kind in ("registration", "subpixel", "refine", "registration_big", "registration_tiny") or desc.get("api") in ("ncc", "pcm_topk"):
+            if kind in ("registration", "subpixel", "refine", "registration_big", "registration_tiny", "featureless") or desc.get("api") in ("ncc", "pcm_topk"):
                 out, st, exp, exp_st = data
                 print(np.concatenate([out, st[:, None], exp, exp_st[:, None]], axis=1))
             else:
