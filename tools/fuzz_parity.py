@@ -177,6 +177,24 @@ def fuzz_apis(rng, reg, fu, oreg, ofu, synth):
 STATS = {}
 
 
+def fuzz_registration_wild(rng, reg, oreg, synth):
+    """Overlaps from 5 to 60 %, jitter up to 20 pixels, any edge width: true shifts far from the nominal one, peaks
+    that need the wrapped interpretations, pairs whose strips hardly overlap at all."""
+    rows, cols = (1, 2) if rng.random() < 0.5 else (2, 1)
+    th, tw = int(rng.integers(40, 260)), int(rng.integers(40, 260))
+    edge = int(rng.integers(4, 200))
+    g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, th, tw, overlap=float(rng.uniform(0.05, 0.6)),
+                        jitter=int(rng.integers(0, 21)))
+    out, st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    exp, exp_st = oreg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, polish=False)
+    ok_rows = exp_st == 0
+    STATS["wild_found_planted"] = STATS.get("wild_found_planted", 0) + int(np.array_equal(exp[:, 1:], g.expected_shift.astype(float)))
+    good = (np.array_equal(st, exp_st) and np.array_equal(out[ok_rows, 1:], exp[ok_rows, 1:])
+            and np.allclose(out[ok_rows, 0], exp[ok_rows, 0], rtol=0, atol=1e-9, equal_nan=True))
+    return bool(good), dict(kind="registration_wild", grid=(rows, cols), tile=(th, tw), edge=edge), (out, st, exp, exp_st)
+
+
 def fuzz_featureless(rng, reg, oreg, synth):
     """Strips whose sampled variance sits at the featureless threshold (2e3): the decision must be the oracle's."""
     th, tw = int(rng.integers(32, 300)), int(rng.integers(32, 300))
@@ -349,7 +367,8 @@ def main():
                "pipeline": lambda: fuzz_pipeline(rng, reg, fu, synth),
                "registration_tiny": lambda: fuzz_registration_tiny(rng, reg, oreg, synth),
                "fusion_tiny": lambda: fuzz_fusion_tiny(rng, fu, ofu, synth),
-               "featureless": lambda: fuzz_featureless(rng, reg, oreg, synth)}
+               "featureless": lambda: fuzz_featureless(rng, reg, oreg, synth),
+               "registration_wild": lambda: fuzz_registration_wild(rng, reg, oreg, synth)}
     kinds = [k for k in runners if not args.only or k in args.only.split(",")]
     counts = {k: 0 for k in kinds}
     last = t0
@@ -359,7 +378,7 @@ def main():
         counts[kind] += 1
         if not good:
             print("DISAGREEMENT", desc, flush=True)
-            if kind in ("registration", "subpixel", "refine", "registration_big", "registration_tiny", "featureless") or desc.get("api") in ("ncc", "pcm_topk"):
+            if kind in ("registration", "subpixel", "refine", "registration_big", "registration_tiny", "featureless", "registration_wild") or desc.get("api") in ("ncc", "pcm_topk"):
                 out, st, exp, exp_st = data
                 print(np.concatenate([out, st[:, None], exp, exp_st[:, None]], axis=1))
             else:
