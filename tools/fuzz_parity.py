@@ -30,7 +30,8 @@ def fuzz_registration(rng, reg, oreg, synth):
         g.tiles[int(rng.integers(rows * cols))] = int(rng.integers(0, 65536))
     # (not a flatfield over a blank tile: constant / smooth is no longer featureless, and its spectrum is zero to
     # rounding in most bins, where the normalised cross-power spectrum is rounding noise in any implementation)
-    flat = synth.make_flatfield(th, tw, amplitude=float(rng.uniform(0, 0.5))) if rng.random() < 0.4 and not blank else None
+    flat = synth.make_flatfield(th, tw, dtype=np.float32 if rng.random() < 0.6 else np.float64,
+                                amplitude=float(rng.uniform(0, 0.95))) if rng.random() < 0.4 and not blank else None
     tiles_for_oracle = g.tiles
     if flat is not None:
         from oracle import fusion as ofu
