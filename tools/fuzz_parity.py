@@ -196,6 +196,32 @@ def fuzz_registration_wild(rng, reg, oreg, synth):
     return bool(good), dict(kind="registration_wild", grid=(rows, cols), tile=(th, tw), edge=edge), (out, st, exp, exp_st)
 
 
+def fuzz_fusion_ff_extreme(rng, fu, ofu, synth):
+    """Flatfield values far outside the range of a real one (tiny, huge, negative, infinite): the kernels leave
+    their scaling-free division for the full one; quotients overflow to the clip or collapse to zero."""
+    th, tw = int(rng.integers(4, 60)), int(rng.integers(4, 90))
+    n = int(rng.integers(1, 12))
+    mh, mw = int(rng.integers(th, 3 * th)), int(rng.integers(tw, 3 * tw))
+    tiles = rng.integers(0, 65536, size=(n, th, tw)).astype(np.uint16)
+    yx = np.stack([rng.integers(0, mh - th // 2, size=n), rng.integers(0, mw - tw // 2, size=n)], axis=1).astype(np.int32)
+    plane = np.zeros(n, dtype=np.int32)
+    dt = np.float32 if rng.random() < 0.7 else np.float64
+    ff = synth.make_flatfield(th, tw, dtype=dt, amplitude=0.3).copy()
+    odd = np.array([1e-7, 1e7, -0.5, 1e-30, 3e38, np.inf, -np.inf, 2.0 ** -17, 2.0 ** 17, 1.0], dtype=dt)
+    where = rng.random((th, tw)) < float(rng.uniform(0.0, 0.3))
+    ff[where] = odd[rng.integers(0, len(odd), size=int(where.sum()))]
+    mode = "overwrite" if rng.random() < 0.5 else "feather"
+    with np.errstate(all="ignore"):
+        want = (ofu.fuse_overwrite if mode == "overwrite" else ofu.fuse_feather)(tiles, yx, plane, 1, mh, mw, flatfields=ff[None],
+                                                                                 tile_ff=plane)
+        want_img = ofu.apply_flatfield(tiles[0], ff)
+    got = fu.fuse_tiles(tiles, yx, plane, 1, mh, mw, flatfields=ff[None], tile_ff=plane, mode=mode).cpu().numpy()
+    got_img = fu.apply_flatfield_to_image(tiles[0], ff)
+    good = np.array_equal(got, want) and np.array_equal(got_img, want_img)
+    return bool(good), dict(kind="fusion_ff_extreme", tile=(th, tw), n=n, mode=mode, dtype=dt.__name__, odd=int(where.sum())), \
+        (got, want, yx, plane)
+
+
 def fuzz_featureless(rng, reg, oreg, synth):
     """Strips whose sampled variance sits at the featureless threshold (2e3): the decision must be the oracle's."""
     th, tw = int(rng.integers(32, 300)), int(rng.integers(32, 300))
@@ -369,7 +395,8 @@ def main():
                "registration_tiny": lambda: fuzz_registration_tiny(rng, reg, oreg, synth),
                "fusion_tiny": lambda: fuzz_fusion_tiny(rng, fu, ofu, synth),
                "featureless": lambda: fuzz_featureless(rng, reg, oreg, synth),
-               "registration_wild": lambda: fuzz_registration_wild(rng, reg, oreg, synth)}
+               "registration_wild": lambda: fuzz_registration_wild(rng, reg, oreg, synth),
+               "fusion_ff_extreme": lambda: fuzz_fusion_ff_extreme(rng, fu, ofu, synth)}
     kinds = [k for k in runners if not args.only or k in args.only.split(",")]
     counts = {k: 0 for k in kinds}
     last = t0
