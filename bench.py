@@ -72,30 +72,9 @@ def union_area(yx, h, w):
 
 def build_device_acquisition(cfg, seed, device):
     """Tiles [C, N, H, W] uint16 cut on the device from white-noise scenes, plus geometry."""
-    import torch
     from image_stitcher_amd import synth
 
-    rows, cols, t, ch = cfg["rows"], cfg["cols"], cfg["tile"], cfg["channels"]
-    jitter = 3
-    pitch = t - int(round(t * 0.10))
-    sh = (rows - 1) * pitch + t + 2 * jitter
-    sw = (cols - 1) * pitch + t + 2 * jitter
-    rng = np.random.default_rng(seed + 7919)
-    jit = rng.integers(-jitter, jitter + 1, size=(rows * cols, 2))
-    jit[0] = 0
-    true_yx = np.array([[jitter + r * pitch + jit[r * cols + c, 0], jitter + c * pitch + jit[r * cols + c, 1]]
-                        for r in range(rows) for c in range(cols)], dtype=np.int64)
-    tiles = torch.empty((ch, rows * cols, t, t), dtype=torch.int16, device=device)
-    gen = torch.Generator(device=device)
-    for c in range(ch):
-        gen.manual_seed(seed * 1000 + c)
-        scene = torch.rand((sh, sw), generator=gen, device=device)
-        scene = (1000.0 + 30000.0 * scene).to(torch.int16)  # <= 31000: same bits as uint16
-        for n, (y0, x0) in enumerate(true_yx):
-            tiles[c, n] = scene[y0:y0 + t, x0:x0 + t]
-        del scene
-    pair_idx, pair_dir = synth.grid_pairs(rows, cols)
-    return tiles.view(torch.uint16), true_yx, pair_idx, pair_dir
+    return synth.make_device_acquisition(cfg["rows"], cfg["cols"], cfg["tile"], cfg["channels"], seed, device)
 
 
 def load_pmc_traffic(workload, fft):

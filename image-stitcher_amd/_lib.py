@@ -62,7 +62,7 @@ def _load() -> C.CDLL:
         "mistitch_refine_pairs": [vp, vp, i32, i32, i32, i64, vp, vp, i32, i32, vp, C.c_double, vp, vp],
         "mistitch_pcm": [vp, vp, i64, vp, i64, i32, i32, u32, vp],
         "mistitch_pcm_topk": [vp, vp, i64, vp, i64, i32, i32, u32, i32, vp, vp, vp],
-        "mistitch_ncc": [vp, vp, i64, vp, i64, i32, i32, vp],
+        "mistitch_ncc": [vp, vp, i64, vp, i64, i32, i32, i32, vp],
         "mistitch_subpixel_shift": [vp, vp, i64, vp, i64, i32, i32, u32, i32, vp],
         "mistitch_set_upsample_factor": [vp, i32],
         "mistitch_edge_variance": [vp, vp, i64, i32, i32, vp],

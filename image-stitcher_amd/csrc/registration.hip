@@ -1856,8 +1856,11 @@ __global__ void k_ups_finish(const PairDesc* desc, const int8_t* status, int pai
 }
 
 // Exact integer moments of two uint16 rows, 8 pixels per lane and step.  Pixels
-// are split into byte planes so that every product is a v_dot4_u32_u8; a lane can
-// take 16,000 steps before a 32-bit partial sum could wrap (callers stay far below).
+// are split into byte planes so that every product is a v_dot4_u32_u8.  The busiest
+// plane (ab_x: two dot products of at most 4 * 255 * 255 per add4) wraps 32 bits after
+// 8256 calls of add4 by one lane: k_ncc_accumulate is bounded by the strip limits
+// (at most 512 rows x 2 groups x 2 calls per lane), the callers without such a bound use
+// moments_of_rows<true>, which empties the planes into 64-bit sums long before that.
 struct __attribute__((packed, aligned(2))) U16x8 {
   unsigned d[4];
 };
@@ -1923,10 +1926,29 @@ struct MomentAcc {
 
 // Rows [r_begin, r_end) step r_step of two windows of ncols pixels; all 256 threads.  Moments
 // summed over each wave come back in v (the same in every lane of a wave).
+// FLUSH: callers whose shapes are not bounded (any patch, any edge width) empty a lane's 32-bit
+// byte-plane sums into 64-bit ones every kFlushEvery groups, long before the busiest plane
+// (two dot products of at most 4 * 255 * 255 per call of add4) can wrap at 8256 calls.
+constexpr int kFlushEvery = 2048;  // calls of add8 = 4096 of add4
+template <bool FLUSH = false>
 __device__ __forceinline__ void moments_of_rows(const uint16_t* a, int64_t pa, const uint16_t* b, int64_t pb,
                                                 int r_begin, int r_end, int r_step, int ncols,
                                                 unsigned long long (&v)[5]) {
   MomentAcc acc;
+  unsigned long long wide[5] = {0, 0, 0, 0, 0};
+  int since = 0;
+  auto flush = [&]() {
+    if constexpr (FLUSH) {
+      if (++since >= kFlushEvery) {
+        unsigned long long t[5];
+        acc.totals(t);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) wide[i] += t[i];
+        acc = MomentAcc();
+        since = 0;
+      }
+    }
+  };
   const int ngroups = ncols >> 3;
   // The columns beyond the last whole group are taken one pixel pair per thread and step, eight
   // threads to a row, apart from the rows' trips; the first step's pixels (all of them, when a
@@ -1956,24 +1978,40 @@ __device__ __forceinline__ void moments_of_rows(const uint16_t* a, int64_t pa, c
           y[k] = *reinterpret_cast<const U16x8*>(rb + (int64_t)k * r_step * pb + 8 * g);
         }
 #pragma unroll
-        for (int k = 0; k < kRows; ++k) acc.add8(x[k], y[k]);
+        for (int k = 0; k < kRows; ++k) {
+          acc.add8(x[k], y[k]);
+          flush();
+        }
       }
     }
   }
   for (; r < r_end; r += r_step) {
     const uint16_t* ra = a + (int64_t)r * pa;
     const uint16_t* rb = b + (int64_t)r * pb;
-    for (int g = threadIdx.x; g < ngroups; g += kThreads)
+    for (int g = threadIdx.x; g < ngroups; g += kThreads) {
       acc.add8(*reinterpret_cast<const U16x8*>(ra + 8 * g), *reinterpret_cast<const U16x8*>(rb + 8 * g));
+      flush();
+    }
   }
   if (tail_first) {
     acc.add1(tail_a, tail_b);
-    for (int rr = tail_row + (kThreads >> 3) * r_step; rr < r_end; rr += (kThreads >> 3) * r_step)
+    for (int rr = tail_row + (kThreads >> 3) * r_step; rr < r_end; rr += (kThreads >> 3) * r_step) {
       acc.add1(a[(int64_t)rr * pa + tail_col], b[(int64_t)rr * pb + tail_col]);
+      flush();
+    }
   }
   const int nrows = r_end > r_begin ? (r_end - r_begin + r_step - 1) / r_step : 0;
   const int steps = 2 * nrows * ((ngroups + kThreads - 1) / kThreads) +
                     (ntail ? (nrows + (kThreads >> 3) - 1) / (kThreads >> 3) : 0);
+  if constexpr (FLUSH) {
+    if (steps > MomentAcc::kWaveSteps32) {  // wave-uniform; below that nothing has been flushed
+      unsigned long long t[5];
+      acc.totals(t);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) v[i] = wave_sum_u64(wide[i] + t[i]);
+      return;
+    }
+  }
   acc.wave_totals(steps, v);
 }
 
@@ -2147,8 +2185,8 @@ __device__ double block_ncc(const PairDesc& d, int ty, int tx, unsigned long lon
   const int s_lo = ds > 0 ? ds : 0, s_hi = d.S + (ds < 0 ? ds : 0);
   const int l_lo = dl > 0 ? dl : 0, l_hi = d.L + (dl < 0 ? dl : 0);
   unsigned long long v[5];
-  moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, s_lo, s_hi, 1,
-                  l_hi - l_lo, v);
+  moments_of_rows<true>(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, s_lo, s_hi, 1,
+                        l_hi - l_lo, v);
   const int wave = threadIdx.x >> 6;
   __syncthreads();  // red may still be read from the previous call
   if ((threadIdx.x & 63) == 0) {
@@ -2236,13 +2274,14 @@ __global__ __launch_bounds__(kThreads) void k_ncc_single(const uint16_t* a, int6
                                                          int h, int w, unsigned long long* acc) {
   __shared__ unsigned long long red[5 * kThreads / 64];
   unsigned long long v[5];
-  moments_of_rows(a, pa, b, pb, blockIdx.x, h, gridDim.x, w, v);
+  moments_of_rows<true>(a, pa, b, pb, blockIdx.x, h, gridDim.x, w, v);
   reduce_moments(v, red, acc);
 }
 
-__global__ void k_ncc_single_finish(const unsigned long long* acc, long long n, double* out) {
+__global__ void k_ncc_single_finish(const unsigned long long* acc, long long n, long long min_n, double* out) {
   if (threadIdx.x == 0 && blockIdx.x == 0)
-    out[0] = n < 25 ? -INFINITY : ncc_from_moments((unsigned long long)n, acc[0], acc[1], acc[2], acc[3], acc[4]);
+    out[0] = (n == 0 || n < min_n) ? -INFINITY
+                                   : ncc_from_moments((unsigned long long)n, acc[0], acc[1], acc[2], acc[3], acc[4]);
 }
 
 __global__ void k_peaks_to_arrays(const Peak* peaks, int k, int img_w, int32_t* rows, int32_t* cols,
@@ -3230,7 +3269,8 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   if ((rc = make_any_shape(ctx, S, L, f64, &cfg))) return rc;
   const int pstride = cfg.nblk * kMaxK;
   RegWorkspace ws;
-  if ((rc = reserve_registration(ctx, 1, 1, 1, (size_t)S * L, cfg.spec_bytes, cfg.slab_bytes, pstride, &ws))) return rc;
+  // the staging slot holds BOTH strips (transposed, or re-pitched) one after the other
+  if ((rc = reserve_registration(ctx, 1, 1, 1, (size_t)2 * S * L, cfg.spec_bytes, cfg.slab_bytes, pstride, &ws))) return rc;
   if (sub_out != nullptr) {
     if ((rc = reserve_subpixel(ctx, 1, 1, cfg.nblk, cfg.n_stored, upsample, &ws))) return rc;
   }
@@ -3358,7 +3398,7 @@ extern "C" int mistitch_set_upsample_factor(mistitch_ctx* ctx, int upsample_fact
 }
 
 extern "C" int mistitch_ncc(mistitch_ctx* ctx, const uint16_t* patch1, int64_t pitch1, const uint16_t* patch2,
-                            int64_t pitch2, int h, int w, double* out) {
+                            int64_t pitch2, int h, int w, int min_overlap_pixels, double* out) {
   MS_REQUIRE(ctx && out, MISTITCH_ERR_ARG, "NULL argument");
   MS_REQUIRE(h >= 0 && w >= 0, MISTITCH_ERR_ARG, "negative size");
   MS_REQUIRE((patch1 && patch2) || h * (long long)w == 0, MISTITCH_ERR_ARG, "NULL patch");
@@ -3372,7 +3412,8 @@ extern "C" int mistitch_ncc(mistitch_ctx* ctx, const uint16_t* patch1, int64_t p
   if ((long long)h * w > 0)
     MS_LAUNCH(ctx, "k_ncc_single", k_ncc_single, dim3(h < 1024 ? h : 1024), dim3(kThreads), 0, patch1, pitch1, patch2, pitch2,
                        h, w, acc);
-  MS_LAUNCH(ctx, "k_ncc_single_finish", k_ncc_single_finish, dim3(1), dim3(64), 0, acc, (long long)h * w, out);
+  MS_LAUNCH(ctx, "k_ncc_single_finish", k_ncc_single_finish, dim3(1), dim3(64), 0, acc, (long long)h * w,
+            (long long)min_overlap_pixels, out);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }

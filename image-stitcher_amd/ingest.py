@@ -76,13 +76,17 @@ class TileStager:
         """Fill and send the bands in turn; yields (band, event) right after a band's copy has
         been enqueued - the event completes when the band is resident."""
         torch = self.torch
+        # A stager may be reused: the kernels of the previous call (on the compute stream) may still
+        # be reading rows of self.tiles that this call's copies overwrite.
+        self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))
         for i, band in enumerate(bands):
             k = i & 1
             n = band.tile1 - band.tile0
             if n > self.pinned[k].shape[0]:
                 raise ValueError(f"band of {n} tiles exceeds the staging buffers ({self.pinned[k].shape[0]})")
-            if i >= 2:
-                self.free[k].synchronize()      # the copy that last read this buffer has finished
+            # the copy that last read this buffer (in this call or the previous one) has finished;
+            # an event that was never recorded is complete
+            self.free[k].synchronize()
             view = self.pinned[k][:n]
             fill(band.tile0, band.tile1, view.numpy().view(np.uint16))
             with torch.cuda.stream(self.copy_stream):

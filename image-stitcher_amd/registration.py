@@ -237,14 +237,14 @@ def _validate_pair(image1, image2) -> None:
         raise ValueError(f"Images must have same shape. Got {image1.shape} and {image2.shape}")
 
 
-def pcm(image1: np.ndarray, image2: np.ndarray, fft: str = "f64") -> np.ndarray:
+def pcm(image1: np.ndarray, image2: np.ndarray, fft: str = "f64", ctx: Optional[_lib.Context] = None) -> np.ndarray:
     """Peak correlation matrix of two uint16 strips (_translation_computation.py:282-340)."""
     torch = _torch()
     _validate_pair(image1, image2)
     a, b = to_device_u16(image1), to_device_u16(image2)
     h, w = (int(s) for s in a.shape)
     out = torch.empty((h, w), dtype=torch.float64, device=a.device)
-    ctx = _lib.default_context()
+    ctx = ctx or _lib.default_context()
     try:
         check(lib.mistitch_pcm(ctx.handle, ptr(a), w, ptr(b), w, h, w, _fft_flag(fft), ptr(out)))
     except _lib.MistitchError as exc:
@@ -252,8 +252,8 @@ def pcm(image1: np.ndarray, image2: np.ndarray, fft: str = "f64") -> np.ndarray:
     return out.cpu().numpy()
 
 
-def pcm_topk(image1: np.ndarray, image2: np.ndarray, k: int = 2, fft: str = "f64"
-             ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+def pcm_topk(image1: np.ndarray, image2: np.ndarray, k: int = 2, fft: str = "f64",
+             ctx: Optional[_lib.Context] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """``multi_peak_max(pcm(a, b), max_peaks=k)`` fused on the device
     (_translation_computation.py:342-441): rows, cols (int64), vals (float64) in
     descending order, equal values by descending flat index."""
@@ -268,14 +268,14 @@ def pcm_topk(image1: np.ndarray, image2: np.ndarray, k: int = 2, fft: str = "f64
     rows = torch.empty((k,), dtype=torch.int32, device=a.device)
     cols = torch.empty((k,), dtype=torch.int32, device=a.device)
     vals = torch.empty((k,), dtype=torch.float64, device=a.device)
-    ctx = _lib.default_context()
+    ctx = ctx or _lib.default_context()
     check(lib.mistitch_pcm_topk(ctx.handle, ptr(a), w, ptr(b), w, h, w, _fft_flag(fft), int(k),
                                 ptr(rows), ptr(cols), ptr(vals)))
     return rows.cpu().numpy().astype(np.int64), cols.cpu().numpy().astype(np.int64), vals.cpu().numpy()
 
 
 def phase_cross_correlation(reference_image: np.ndarray, moving_image: np.ndarray, upsample_factor: int = 100,
-                            fft: str = "f64") -> np.ndarray:
+                            fft: str = "f64", ctx: Optional[_lib.Context] = None) -> np.ndarray:
     """Shift (dy, dx) registering ``moving_image`` onto ``reference_image`` by upsampled DFT: what
     ``skimage.registration.phase_cross_correlation(a, b, upsample_factor=u, normalization='phase')``
     returns as its first result, as called at _translation_computation.py:1239-1247."""
@@ -284,7 +284,7 @@ def phase_cross_correlation(reference_image: np.ndarray, moving_image: np.ndarra
     a, b = to_device_u16(reference_image), to_device_u16(moving_image)
     h, w = (int(s) for s in a.shape)
     out = torch.empty((2,), dtype=torch.float64, device=a.device)
-    ctx = _lib.default_context()
+    ctx = ctx or _lib.default_context()
     check(lib.mistitch_subpixel_shift(ctx.handle, ptr(a), w, ptr(b), w, h, w, _fft_flag(fft), int(upsample_factor),
                                       ptr(out)))
     return out.cpu().numpy()
@@ -305,11 +305,8 @@ def ncc(image1: np.ndarray, image2: np.ndarray, min_overlap_pixels: int = 25) ->
     h, w = (int(s) for s in a.shape)
     out = torch.empty((1,), dtype=torch.float64, device=a.device)
     ctx = _lib.default_context()
-    check(lib.mistitch_ncc(ctx.handle, ptr(a), w, ptr(b), w, h, w, ptr(out)))
-    v = float(out.cpu()[0])
-    if n < 25 <= min_overlap_pixels:
-        return float("-inf")
-    return v
+    check(lib.mistitch_ncc(ctx.handle, ptr(a), w, ptr(b), w, h, w, int(min_overlap_pixels), ptr(out)))
+    return float(out.cpu()[0])
 
 
 def edge_variance(edge: np.ndarray) -> float:

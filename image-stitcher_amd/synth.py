@@ -87,3 +87,46 @@ def make_grid(seed: int, rows: int, cols: int, tile_h: int, tile_w: int,
             tiles[t] = scene[y0:y0 + tile_h, x0:x0 + tile_w]
     pair_idx, pair_dir = grid_pairs(rows, cols)
     return SyntheticGrid(tiles, true_yx, rows, cols, pitch_y, pitch_x, pair_idx, pair_dir)
+
+
+def planted_positions(seed: int, rows: int, cols: int, tile: int, overlap: float = 0.10, jitter: int = 3):
+    """(true_yx [N, 2] int64, scene_h, scene_w) of a jittered grid, the arithmetic of ``make_grid``."""
+    pitch = tile - int(round(tile * overlap))
+    sh = (rows - 1) * pitch + tile + 2 * jitter
+    sw = (cols - 1) * pitch + tile + 2 * jitter
+    rng = np.random.default_rng(seed + 7919)
+    jit = rng.integers(-jitter, jitter + 1, size=(rows * cols, 2))
+    jit[0] = 0
+    true_yx = np.array([[jitter + r * pitch + jit[r * cols + c, 0], jitter + c * pitch + jit[r * cols + c, 1]]
+                        for r in range(rows) for c in range(cols)], dtype=np.int64)
+    return true_yx, sh, sw
+
+
+def make_device_acquisition(rows: int, cols: int, tile: int, channels: int, seed: int, device,
+                            keep_scenes: bool = False, scene_seeds=None):
+    """Tiles ``[C, N, H, W]`` uint16 cut ON THE DEVICE from white-noise scenes (one per channel),
+    with the planted geometry: (tiles, true_yx, pair_idx, pair_dir[, scenes]); ``keep_scenes`` is
+    True (all) or the channel indices whose scenes to return.  Full-size
+    acquisitions (13 GB for a 20 x 20 x 4 grid) never exist on the host."""
+    import torch
+
+    true_yx, sh, sw = planted_positions(seed, rows, cols, tile)
+    tiles = torch.empty((channels, rows * cols, tile, tile), dtype=torch.int16, device=device)
+    gen = torch.Generator(device=device)
+    scenes = []
+    band = 4096
+    for c in range(channels):
+        gen.manual_seed(seed * 1000 + c if scene_seeds is None else int(scene_seeds[c]))
+        scene = torch.empty((sh, sw), dtype=torch.int16, device=device)
+        for y in range(0, sh, band):  # in bands: the float32 scene never exists whole
+            h = min(band, sh - y)
+            scene[y:y + h] = (1000.0 + 30000.0 * torch.rand((h, sw), generator=gen, device=device)).to(torch.int16)
+        for n, (y0, x0) in enumerate(true_yx):  # values <= 31000: same bits as uint16
+            tiles[c, n] = scene[y0:y0 + tile, x0:x0 + tile]
+        if keep_scenes is True or (keep_scenes and c in keep_scenes):
+            scenes.append(scene.view(torch.uint16))
+        del scene
+    pair_idx, pair_dir = grid_pairs(rows, cols)
+    if keep_scenes:
+        return tiles.view(torch.uint16), true_yx, pair_idx, pair_dir, scenes
+    return tiles.view(torch.uint16), true_yx, pair_idx, pair_dir

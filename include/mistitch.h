@@ -176,10 +176,11 @@ int mistitch_pcm_topk(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1,
                       int32_t* rows, int32_t* cols, double* vals);
 
 /* Pearson correlation of two h x w uint16 patches, exact integer moments.
- * Replaces ncc() (_translation_computation.py:535-616); -inf when h*w < 25.
+ * Replaces ncc(image1, image2, min_overlap_pixels) (_translation_computation.py:535-616):
+ * -inf for an empty patch or when h*w < min_overlap_pixels (the reference's default is 25).
  *   out        [1] float64                                                      */
 int mistitch_ncc(mistitch_ctx* ctx, const uint16_t* patch1, int64_t pitch1, const uint16_t* patch2,
-                 int64_t pitch2, int h, int w, double* out);
+                 int64_t pitch2, int h, int w, int min_overlap_pixels, double* out);
 
 /* The strip variance test of is_edge_featureless (tile_registration.py:497-525):
  * population variance of every 16th sample in both directions.

@@ -354,3 +354,70 @@ def test_tall_strips_take_the_wide_accumulators(reg):
     b = (a // 2 + rng.integers(0, 30000, size=a.shape)).astype(np.uint16)
     assert abs(reg.ncc(a, b) - oreg.ncc(a, b)) < 1e-12
     assert abs(reg.ncc(a[:, :5], b[:, :5]) - oreg.ncc(a[:, :5], b[:, :5])) < 1e-12
+
+
+def test_single_pair_calls_on_a_fresh_context(reg):
+    """pcm / pcm_topk / phase_cross_correlation stage BOTH strips of a tall pair (and of a pair
+    with two different row pitches) in the context's staging buffer: on a context that no batched
+    call has grown before, that buffer has its minimum size."""
+    import torch
+    from image_stitcher_amd import _lib
+    from image_stitcher_amd._lib import check, lib, ptr_of
+    from oracle import subpixel as osp
+    h, w = 2048, 195
+    big = synth.make_scene(612, h + 16, w + 16)
+    a = np.ascontiguousarray(big[8:8 + h, 8:8 + w])
+    b = np.ascontiguousarray(big[8 + 2:8 + 2 + h, 8 - 3:8 - 3 + w])
+    ref = oreg.pcm(a, b)
+    for call in ("pcm", "topk", "subpixel"):
+        fresh = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+        # a canary right behind whatever the library allocates next is not possible from here; the
+        # results themselves and a clean device afterwards are what is checked
+        if call == "pcm":
+            assert np.abs(reg.pcm(a, b, ctx=fresh) - ref).max() < 1e-11
+        elif call == "topk":
+            rows, cols, vals = reg.pcm_topk(a, b, 2, ctx=fresh)
+            er, ec, ev = oreg.multi_peak_max(ref)
+            assert (rows[0], cols[0]) == (er[0], ec[0]) and vals[0] == pytest.approx(ev[0], abs=1e-11)
+        else:
+            got = reg.phase_cross_correlation(a, b, 100, ctx=fresh)
+            assert np.abs(got - osp.phase_cross_correlation(a, b, 100)).max() <= 0.01 + 1e-9
+        fresh.synchronize()
+        fresh.close()
+    # two different row pitches: both strips are re-pitched into the staging buffer
+    hh, ww = 64, 256
+    wide1 = torch.from_numpy(synth.make_scene(613, hh + 8, ww + 40).view(np.int16)).cuda()
+    wide2 = torch.from_numpy(synth.make_scene(614, hh + 8, ww + 104).view(np.int16)).cuda()
+    s1, s2 = wide1[:hh, 8:8 + ww], wide2[:hh, 16:16 + ww]
+    fresh = _lib.Context(0, torch.cuda.current_stream().cuda_stream)
+    out = torch.empty((hh, ww), dtype=torch.float64, device="cuda")
+    check(lib.mistitch_pcm(fresh.handle, ptr_of(s1), ww + 40, ptr_of(s2), ww + 104, hh, ww, 0, ptr_of(out)))
+    want = oreg.pcm(s1.cpu().numpy().view(np.uint16), s2.cpu().numpy().view(np.uint16))
+    assert np.abs(out.cpu().numpy() - want).max() < 1e-11
+    fresh.close()
+
+
+def test_ncc_threshold_and_saturated_patches(reg):
+    """min_overlap_pixels below the default is honoured (_translation_computation.py:567-569), and
+    patches of almost only 0xFFFF pixels, long enough that a lane's 32-bit byte-plane sums would
+    wrap without the periodic flush into 64 bits, still give the exact correlation."""
+    rng = np.random.default_rng(77)
+    a = rng.integers(0, 65535, size=(4, 4)).astype(np.uint16)
+    b = rng.integers(0, 65535, size=(4, 4)).astype(np.uint16)
+    assert reg.ncc(a, b) == float("-inf")                          # 16 < 25
+    assert reg.ncc(a, b, min_overlap_pixels=4) == pytest.approx(oreg.ncc(a, b, min_overlap_pixels=4), abs=1e-13)
+    assert reg.ncc(a, b, min_overlap_pixels=17) == float("-inf")
+    for shape in ((1, 12_000_000), (3, 9_000_001)):
+        x = np.full(shape, 0xFFFF, dtype=np.uint16)
+        y = np.full(shape, 0xFFFF, dtype=np.uint16)
+        idx = rng.integers(0, shape[1], size=4000)
+        x[0, idx] = rng.integers(0, 65535, size=4000)
+        y[0, idx[:3000]] = x[0, idx[:3000]] // 2
+        y[-1, rng.integers(0, shape[1], size=500)] = 7
+        # exact reference from integer moments (Python integers)
+        xi, yi = x.astype(np.int64).ravel(), y.astype(np.int64).ravel()
+        n = xi.size
+        sa, sb = int(xi.sum()), int(yi.sum())
+        saa, sbb, sab = int((xi * xi).sum()), int((yi * yi).sum()), int((xi * yi).sum())
+        want = (n * sab - sa * sb) / (float(n * saa - sa * sa) ** 0.5 * float(n * sbb - sb * sb) ** 0.5)
+        assert reg.ncc(x, y) == pytest.approx(want, abs=1e-12), shape
