@@ -32,7 +32,7 @@ EXPORTS = [
     "mistitch_apply_flatfield", "mistitch_fuse", "mistitch_mip", "mistitch_synchronize",
     "mistitch_profile_enable", "mistitch_profile_collect", "mistitch_subpixel_shift",
     "mistitch_set_upsample_factor", "mistitch_pyramid", "mistitch_refine_pairs",
-    "mistitch_register_pairs_flatfield",
+    "mistitch_register_pairs_flatfield", "mistitch_fuse_static",
 ]
 
 
@@ -68,6 +68,7 @@ def _load() -> C.CDLL:
         "mistitch_edge_variance": [vp, vp, i64, i32, i32, vp],
         "mistitch_apply_flatfield": [vp, vp, vp, i32, vp, i32, i32, i32],
         "mistitch_fuse": [vp, vp, i32, i32, i32, i64, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32],
+        "mistitch_fuse_static": [vp, vp, i32, i32, i32, i64, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32],
         "mistitch_mip": [vp, vp, i32, i64, i64, vp],
         "mistitch_pyramid": [vp, vp, i32, i32, i32, i32, C.POINTER(vp)],
         "mistitch_synchronize": [vp],

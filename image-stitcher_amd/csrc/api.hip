@@ -3,7 +3,11 @@
 
 using namespace mistitch;
 
-extern "C" int mistitch_version(void) { return 100; }
+namespace mistitch {
+int fuse_static_setup(int device);  // fusion.hip: address of this device's static workspace
+}
+
+extern "C" int mistitch_version(void) { return 101; }
 
 extern "C" const char* mistitch_last_error(void) { return last_error_buf(); }
 
@@ -14,6 +18,8 @@ extern "C" int mistitch_create(int device, void* stream, mistitch_ctx** out) {
   MS_HIP(hipGetDeviceCount(&count));
   MS_REQUIRE(device >= 0 && device < count, MISTITCH_ERR_ARG, "device %d not in [0, %d)", device, count);
   MS_HIP(hipSetDevice(device));
+  int rc = fuse_static_setup(device);
+  if (rc != MISTITCH_OK) return rc;
   mistitch_ctx* ctx = new mistitch_ctx();
   ctx->device = device;
   ctx->stream = reinterpret_cast<hipStream_t>(stream);

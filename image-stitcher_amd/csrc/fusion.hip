@@ -881,10 +881,34 @@ static void launch_fuse(mistitch_ctx* ctx, dim3 grid, const uint16_t* tiles, int
 
 using namespace mistitch;
 
-extern "C" int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
-                             int64_t tile_pitch, const int32_t* tile_yx, const int32_t* tile_plane,
-                             const void* flatfields, int ff_type, const int32_t* tile_ff, uint16_t* mosaic,
-                             int n_planes, int mosaic_h, int mosaic_w, int row0, int row1, int mode) {
+// Workspace of the allocation-free entry point: the per-block tile lists of ONE fusion call.  Every GPU
+// the library runs on holds its own copy of the array at its own address (hipGetSymbolAddress with that
+// device current); host code never passes the array's name to a kernel, only those addresses.
+constexpr size_t kStaticScratchBytes = 16u << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+constexpr int kMaxDevices = 64;
+static void* g_scratch_of_device[kMaxDevices];  // filled by fuse_static_setup, one entry per device
+
+namespace mistitch {
+// Called by mistitch_create with `device` current: looks up this device's copy of `scratch` once.
+int fuse_static_setup(int device) {
+  MS_REQUIRE(device >= 0 && device < kMaxDevices, MISTITCH_ERR_UNSUPPORTED, "device index %d beyond %d", device,
+             kMaxDevices - 1);
+  if (__atomic_load_n(&g_scratch_of_device[device], __ATOMIC_ACQUIRE) != nullptr) return MISTITCH_OK;
+  void* p = nullptr;
+  MS_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+  MS_REQUIRE(p != nullptr, MISTITCH_ERR_HIP, "hipGetSymbolAddress returned no address for device %d", device);
+  __atomic_store_n(&g_scratch_of_device[device], p, __ATOMIC_RELEASE);  // every caller computes the same value
+  return MISTITCH_OK;
+}
+}  // namespace mistitch
+
+// Body of mistitch_fuse / mistitch_fuse_static.  `static_ws`: this device's copy of `scratch`, or NULL to
+// take (and if need be grow) the context's own buffer.
+static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w, int64_t tile_pitch,
+                     const int32_t* tile_yx, const int32_t* tile_plane, const void* flatfields, int ff_type,
+                     const int32_t* tile_ff, uint16_t* mosaic, int n_planes, int mosaic_h, int mosaic_w, int row0,
+                     int row1, int mode, void* static_ws) {
   MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
   MS_REQUIRE(mosaic, MISTITCH_ERR_ARG, "mosaic is NULL");
   MS_REQUIRE(n_tiles >= 0 && n_planes > 0 && mosaic_h > 0 && mosaic_w > 0, MISTITCH_ERR_ARG, "bad mosaic geometry");
@@ -905,11 +929,23 @@ extern "C" int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_til
   const int64_t n_blocks = (int64_t)grid.x * grid.y * grid.z;
   int rc;
   const size_t bins_bytes = (size_t)n_blocks * (kMaxCand + 1) * sizeof(int32_t);
-  if ((rc = ctx->bins.reserve(bins_bytes + 16))) return rc;
-  const int32_t* bins = reinterpret_cast<const int32_t*>(ctx->bins.ptr);
-  int32_t* ff_safe = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ctx->bins.ptr) + bins_bytes);
+  void* ws = static_ws;
+  if (ws != nullptr) {
+    MS_REQUIRE(bins_bytes + 16 <= kStaticScratchBytes, MISTITCH_ERR_UNSUPPORTED,
+               "mistitch_fuse_static: %lld output blocks of %d x %d pixels need %zu bytes of tile lists, the static "
+               "workspace holds %zu (about %lld blocks): fuse fewer rows per call, or call mistitch_fuse",
+               (long long)n_blocks, kBH, 512 * GX, bins_bytes + 16, kStaticScratchBytes,
+               (long long)((kStaticScratchBytes - 16) / ((kMaxCand + 1) * sizeof(int32_t))));
+  } else {
+    if ((rc = ctx->bins.reserve(bins_bytes + 16))) return rc;
+    ws = ctx->bins.ptr;
+  }
+  // nothing in the workspace has to start at zero: k_fuse_bins writes every block's count and list and the
+  // flatfield verdict before anything reads them
+  const int32_t* bins = reinterpret_cast<const int32_t*>(ws);
+  int32_t* ff_safe = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + bins_bytes);
   MS_LAUNCH(ctx, "k_fuse_bins", k_fuse_bins, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, n_tiles, tile_h, tile_w,
-            tile_yx, tile_plane, reinterpret_cast<int32_t*>(ctx->bins.ptr), (int)grid.x, (int)grid.y, n_planes, mosaic_w,
+            tile_yx, tile_plane, reinterpret_cast<int32_t*>(ws), (int)grid.x, (int)grid.y, n_planes, mosaic_w,
             row0, row1, 512 * GX, ff_safe);
   if (ff_type == MISTITCH_FF_F32 && n_tiles > 0)
     MS_LAUNCH(ctx, "k_ff_check", k_ff_check, dim3(kFfChunks, kFfPlanes), dim3(256), 0,
@@ -929,6 +965,27 @@ extern "C" int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_til
 #undef MS_FUSE
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
+}
+
+extern "C" int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
+                             int64_t tile_pitch, const int32_t* tile_yx, const int32_t* tile_plane,
+                             const void* flatfields, int ff_type, const int32_t* tile_ff, uint16_t* mosaic,
+                             int n_planes, int mosaic_h, int mosaic_w, int row0, int row1, int mode) {
+  return fuse_impl(ctx, tiles, n_tiles, tile_h, tile_w, tile_pitch, tile_yx, tile_plane, flatfields, ff_type, tile_ff,
+                   mosaic, n_planes, mosaic_h, mosaic_w, row0, row1, mode, nullptr);
+}
+
+extern "C" int mistitch_fuse_static(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
+                                    int64_t tile_pitch, const int32_t* tile_yx, const int32_t* tile_plane,
+                                    const void* flatfields, int ff_type, const int32_t* tile_ff, uint16_t* mosaic,
+                                    int n_planes, int mosaic_h, int mosaic_w, int row0, int row1, int mode) {
+  MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
+  MS_REQUIRE(ctx->device >= 0 && ctx->device < kMaxDevices, MISTITCH_ERR_UNSUPPORTED, "device index %d beyond %d",
+             ctx->device, kMaxDevices - 1);
+  void* ws = __atomic_load_n(&g_scratch_of_device[ctx->device], __ATOMIC_ACQUIRE);
+  MS_REQUIRE(ws != nullptr, MISTITCH_ERR_HIP, "the static workspace of device %d was never looked up", ctx->device);
+  return fuse_impl(ctx, tiles, n_tiles, tile_h, tile_w, tile_pitch, tile_yx, tile_plane, flatfields, ff_type, tile_ff,
+                   mosaic, n_planes, mosaic_h, mosaic_w, row0, row1, mode, ws);
 }
 
 extern "C" int mistitch_apply_flatfield(mistitch_ctx* ctx, const uint16_t* in, const void* flatfield, int ff_type,

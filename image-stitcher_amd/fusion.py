@@ -139,7 +139,7 @@ def generate_pyramid(image, num_levels: int):
 
 def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_w: int,
                flatfields=None, tile_ff=None, mode: str = "overwrite", rows: Optional[Tuple[int, int]] = None,
-               out=None, ctx: Optional[_lib.Context] = None):
+               out=None, ctx: Optional[_lib.Context] = None, static_workspace: bool = False):
     """Fuse tiles (given IN PLACEMENT ORDER) into ``[n_planes, mosaic_h, mosaic_w]`` uint16.
 
     tiles      [T, H, W] uint16 (CUDA tensor, or NumPy array that is uploaded)
@@ -147,6 +147,8 @@ def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_
     tile_plane [T] int32 destination plane (channel * Z + z)
     flatfields [F, H, W] float32/float64 or None; tile_ff [T] int32 plane per tile (-1 none)
     rows       (row0, row1): only this band of every plane is written (multi-GPU sharding)
+    static_workspace  call ``mistitch_fuse_static``: no device allocation inside the library
+                      (``out`` should then be given too); fails beyond its size limit
     """
     torch = _torch()
     tiles = to_device_u16(tiles)
@@ -177,8 +179,9 @@ def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_
     row0, row1 = (0, mosaic_h) if rows is None else (int(rows[0]), int(rows[1]))
     mode_id = {"overwrite": FUSE_OVERWRITE, "feather": FUSE_FEATHER}[mode]
     ctx = ctx or _lib.default_context()
-    check(lib.mistitch_fuse(ctx.handle, ptr(tiles), n_tiles, h, w, h * w, ptr(yx), ptr(pl), ptr(ff), _ff_type(ff),
-                            ptr(tff), ptr(out), int(n_planes), int(mosaic_h), int(mosaic_w), row0, row1, mode_id))
+    entry = lib.mistitch_fuse_static if static_workspace else lib.mistitch_fuse
+    check(entry(ctx.handle, ptr(tiles), n_tiles, h, w, h * w, ptr(yx), ptr(pl), ptr(ff), _ff_type(ff),
+                ptr(tff), ptr(out), int(n_planes), int(mosaic_h), int(mosaic_w), row0, row1, mode_id))
     return out
 
 

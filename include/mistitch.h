@@ -88,7 +88,10 @@ int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int
  * Replaces the serial pair loop of process_neighborhood_batch
  * (tile_registration.py:310-378) and, per pair, compute_single_translation
  * (tile_registration.py:527-586): featureless test, phase correlation, peak
- * ranking, 16-candidate NCC search over the two best peaks.
+ * ranking, 16-candidate NCC search over the two best peaks.  Results equal the
+ * reference's only where its RANSAC branch (interpret_translation_ransac "Method 1",
+ * _translation_computation.py:1197-1230, needs scikit-image) is inactive; with that
+ * branch active the reference may return a consensus shift instead: parity unpinned.
  *
  *   tiles      [n_tiles] images of tile_h x tile_w uint16, row-major, image t at
  *              tiles + t * tile_pitch (elements)
@@ -215,6 +218,22 @@ int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int til
                   int64_t tile_pitch, const int32_t* tile_yx, const int32_t* tile_plane,
                   const void* flatfields, int ff_type, const int32_t* tile_ff, uint16_t* mosaic,
                   int n_planes, int mosaic_h, int mosaic_w, int row0, int row1, int mode);
+
+/* mistitch_fuse for callers that cannot allocate device memory: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * Same arguments and results as mistitch_fuse, but the per-block tile lists live in a 16 MiB
+ * array that is part of the library's code object (one copy per GPU, held until the process
+ * ends) instead of the context's grow-only buffer: the call makes no hipMalloc / hipFree.
+ * Limit: (number of 32-row x 2048-pixel output blocks of rows [row0, row1) over all planes)
+ * * 132 + 16 bytes <= 16 MiB, i.e. about 127 000 blocks or 8.3 gigapixels per call (the
+ * 4 x 37 070 x 37 071 mosaic of a 20 x 20 x 4 acquisition needs 11.7 MB); beyond it the call
+ * fails with MISTITCH_ERR_UNSUPPORTED and writes nothing - fuse in row bands then.
+ * All contexts of one GPU share that array: calls that overlap on one GPU (different streams
+ * or threads) race; calls on one stream are safe back to back.                             */
+int mistitch_fuse_static(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
+                         int64_t tile_pitch, const int32_t* tile_yx, const int32_t* tile_plane,
+                         const void* flatfields, int ff_type, const int32_t* tile_ff, uint16_t* mosaic,
+                         int n_planes, int mosaic_h, int mosaic_w, int row0, int row1, int mode);
 
 /* Per-pixel maximum over `n` images of h*w uint16 (image i at in + i*pitch).
  * Replaces Stitcher.compute_mip (stitcher.py:102-121).                           */
