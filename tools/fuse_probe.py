@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--overlap", type=float, default=0.1)
     ap.add_argument("--jitter", type=int, default=7)
     ap.add_argument("--only", default="", help="run one variant only, e.g. feather:f32")
+    ap.add_argument("--kernels", action="store_true", help="per-kernel milliseconds of one more call")
     ap.add_argument("--align", type=int, default=1, help="round tile columns down to a multiple of this")
     args = ap.parse_args()
     import torch
@@ -59,6 +60,11 @@ def main():
             feather_bytes = ch * (2 * n * t * t + 2 * mh * mw)
             print(f"{mode_name:9s} ff={ff_name:4s} {ms:8.3f} ms  {feather_bytes / ms / 1e6:8.1f} GB/s (2B*tile px + 2B*out px)",
                   flush=True)
+            if args.kernels:
+                ctx.profile(True)
+                run()
+                print("   " + "  ".join(f"{k} {v[0]:.3f}" for k, v in ctx.profile_collect().items()), flush=True)
+                ctx.profile(False)
 
 
 if __name__ == "__main__":

@@ -103,8 +103,8 @@ static void run(const char* name, size_t bytes_moved, F launch) {
   fflush(stdout);
 }
 
-int main() {
-  const size_t bytes = (size_t)6 << 30;
+int main(int argc, char** argv) {
+  const size_t bytes = (size_t)(argc > 1 ? atoi(argv[1]) : 6) << 30;
   const size_t n = bytes / 16;
   u4 *src, *dst;
   CK(hipMalloc(&src, bytes));
