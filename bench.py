@@ -8,8 +8,13 @@ fuse all channels with flatfield correction into the mosaic.  Registration and
 fusion are timed in separate bracketed regions of K steps each because the
 metric has two units (tile pairs/s and fused MPix/s).
 
-Scaling is weak: every rank owns one whole acquisition (an independent region,
-as wells or timepoints are), so `value` sums over ranks.
+N > 1 shards ONE acquisition (strong scaling, the default): rank r registers its
+contiguous run of the pair list (the tiles of those grid rows and the halo row
+above them are resident), one all-gather hands every rank all pair rows, every rank solves
+the positions, and rank r fuses its band of mosaic chunk rows from the tiles
+that touch it.  `value` = pairs of the whole grid / the slowest rank's time.
+`--scaling weak` runs N independent replicas instead (one acquisition per GPU,
+no exchange).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|small]
 
@@ -55,6 +60,11 @@ def parse_args():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="multi-rank rehearsal on ONE GPU: gloo backend, every rank on device 0 (not a measurement)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: shard one acquisition over the ranks (strong) or one acquisition per rank (weak)")
+    ap.add_argument("--band-align", type=int, default=256,
+                    help="mosaic row bands of the ranks are multiples of this many rows (the reference writes chunks of "
+                         "min(H, 12288) rows, parameters.py:695-701: a writer gathers whole bands per chunk)")
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side figures (other fusion mode, other FFT precision): profiler runs")
     return ap.parse_args()
@@ -70,30 +80,60 @@ def union_area(yx, h, w):
     return int((np.diff(ys)[:, None] * np.diff(xs)[None, :] * grid).sum())
 
 
-def build_device_acquisition(cfg, seed, device):
-    """Tiles [C, N, H, W] uint16 cut on the device from white-noise scenes, plus geometry."""
-    from image_stitcher_amd import synth
-
-    return synth.make_device_acquisition(cfg["rows"], cfg["cols"], cfg["tile"], cfg["channels"], seed, device)
+def kernel_source_hash():
+    """sha256 over the kernel sources (the stamp tools/pmc_summary.py puts into profiles/pmc_traffic.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "image-stitcher_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".hpp", ".h")):
+            with open(os.path.join(src, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()
 
 
 def load_pmc_traffic(workload, fft):
-    """HBM bytes per launch of each kernel, from the committed rocprofv3 --pmc passes
-    (2 x FETCH_SIZE + WRITE_SIZE, see tools/pmc_summary.py); {} when none is recorded.
-    Counters cannot be collected from inside this process, so they are measured by
-    separate profiler runs of this same command and read back here."""
+    """(HBM bytes per launch of each kernel, note) from the committed rocprofv3 --pmc passes
+    (2 x FETCH_SIZE + WRITE_SIZE, see tools/pmc_summary.py).  Counters cannot be collected from
+    inside this process, so they are measured by separate profiler runs of this same command
+    and read back here; they are only reported while the kernel sources are the ones that
+    were profiled (same hash), otherwise traffic is null."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
-        return {}
+        return {}, "no profiles/pmc_traffic.json"
     with open(path) as fh:
         doc = json.load(fh)
     if doc.get("workload") != workload or doc.get("fft") != fft:
-        return {}
-    return {k: v["hbm_bytes_per_launch"] for k, v in doc.get("kernels", {}).items()}
+        return {}, "profiles/pmc_traffic.json was collected on another workload or FFT precision"
+    if doc.get("kernel_source_sha256") != kernel_source_hash():
+        return {}, "profiles/pmc_traffic.json is stale: the kernel sources changed since the counter passes"
+    return {k: v["hbm_bytes_per_launch"] for k, v in doc.get("kernels", {}).items()}, \
+        f"rocprofv3 --pmc passes of this command ({doc.get('tag')}), kernel sources unchanged since"
+
+
+def _cpu_worker_init(shm_name, shape):
+    """Pool initialiser: attach the corrected tiles the parent placed in shared memory."""
+    from multiprocessing import shared_memory
+    global _W_SHM, _W_TILES
+    _W_SHM = shared_memory.SharedMemory(name=shm_name)
+    _W_TILES = np.ndarray(shape, dtype=np.uint16, buffer=_W_SHM.buf)
+
+
+def _cpu_worker_register(job):
+    from oracle import registration as oreg
+    pair_idx, pair_dir, edge_width = job
+    if len(pair_idx) == 0:
+        return 0
+    oreg.register_pairs(_W_TILES, pair_idx, pair_dir, edge_width, polish=True)
+    return len(pair_idx)
 
 
 def cpu_baseline(n_pairs_target, edge_width, tile, fuse_mode, with_ff):
-    """Time the NumPy oracle (single thread, serial loops, as the reference runs) on a bounded sample."""
+    """Time the NumPy oracle on a bounded sample: one core with serial loops (as the reference runs),
+    then the same pairs spread over worker PROCESSES, one per core this job may use.  Called before
+    anything touches the GPU, so the children are ordinary spawned interpreters."""
+    import multiprocessing as mp
+    from multiprocessing import shared_memory
     from image_stitcher_amd import synth
     from oracle import fusion as ofu
     from oracle import registration as oreg
@@ -108,16 +148,24 @@ def cpu_baseline(n_pairs_target, edge_width, tile, fuse_mode, with_ff):
     corrected = np.stack([ofu.apply_flatfield(x, ff) for x in g.tiles]) if with_ff else g.tiles
     out, _ = oreg.register_pairs(corrected, g.pair_idx[:n], g.pair_dir[:n], edge_width, polish=True)
     t_reg = time.perf_counter() - t0
-    # the same pairs again, spread over the host cores this process may use (threads: NumPy drops the
-    # GIL inside its FFTs, sorts and reductions; no child process is started once the GPU is in use)
-    from concurrent.futures import ThreadPoolExecutor
-    n_thr = max(1, min(16, os.cpu_count() or 1, n))
-    slices = [np.arange(i, n, n_thr) for i in range(n_thr)]
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(n_thr) as pool:
-        list(pool.map(lambda ix: oreg.register_pairs(corrected, g.pair_idx[ix], g.pair_dir[ix], edge_width, polish=True),
-                      slices))
-    t_reg_threads = time.perf_counter() - t0
+    # all cores: the box gives a one-GPU job 16 CPUs (os.cpu_count() shows the whole machine)
+    n_proc = max(1, min(16, os.cpu_count() or 1, n))
+    t_reg_procs = None
+    shm = shared_memory.SharedMemory(create=True, size=corrected.nbytes)
+    try:
+        np.ndarray(corrected.shape, dtype=np.uint16, buffer=shm.buf)[:] = corrected
+        slices = [np.arange(i, n, n_proc) for i in range(n_proc)]
+        jobs = [(g.pair_idx[ix], g.pair_dir[ix], edge_width) for ix in slices]
+        warm = [(g.pair_idx[:0], g.pair_dir[:0], edge_width)] * n_proc
+        with mp.get_context("spawn").Pool(n_proc, initializer=_cpu_worker_init, initargs=(shm.name, corrected.shape)) as pool:
+            pool.map(_cpu_worker_register, warm, chunksize=1)      # interpreters up, modules imported
+            t0 = time.perf_counter()
+            done = sum(pool.map(_cpu_worker_register, jobs, chunksize=1))
+            t_reg_procs = time.perf_counter() - t0
+            assert done == n
+    finally:
+        shm.close()
+        shm.unlink()
     yx = (g.true_yx - g.true_yx.min(axis=0)).astype(np.int32)
     mh, mw = int(yx[:, 0].max()) + tile, int(yx[:, 1].max()) + tile
     plane = np.zeros(len(g.tiles), dtype=np.int32)
@@ -129,17 +177,54 @@ def cpu_baseline(n_pairs_target, edge_width, tile, fuse_mode, with_ff):
     t_fuse = time.perf_counter() - t0
     mpix = union_area(yx[:nf], tile, tile) / 1e6
     return dict(pairs=n, t_reg=t_reg, t_fuse=t_fuse, fused_mpix=mpix, tiles_fused=nf, grid_side=side,
-                t_reg_threads=t_reg_threads, threads=n_thr)
+                t_reg_procs=t_reg_procs, procs=n_proc)
+
+
+def band_bytes(yx, tile, band_h, mosaic_w, ch, with_ff):
+    """Algorithmic bytes of fusing one band of ``band_h`` rows (tile positions relative to the band):
+    feather = 2 B x tile pixels inside the band + 2 B x band pixels; overwrite = 4 B x covered + 2 B x
+    uncovered band pixels; plus the flatfield planes once."""
+    clipped = []
+    tile_px = 0
+    for y, x in yx:
+        y0, y1 = max(int(y), 0), min(int(y) + tile, band_h)
+        if y1 > y0:
+            clipped.append((y0, y1, int(x), int(x) + tile))
+            tile_px += (y1 - y0) * tile
+    covered = 0
+    if clipped:
+        ys = np.unique([v for r in clipped for v in r[:2]])
+        xs = np.unique([v for r in clipped for v in r[2:]])
+        grid = np.zeros((len(ys) - 1, len(xs) - 1), dtype=bool)
+        for y0, y1, x0, x1 in clipped:
+            grid[np.searchsorted(ys, y0):np.searchsorted(ys, y1), np.searchsorted(xs, x0):np.searchsorted(xs, x1)] = True
+        covered = int((np.diff(ys)[:, None] * np.diff(xs)[None, :] * grid).sum())
+    band_px = band_h * mosaic_w
+    out = {"feather": ch * (2 * tile_px + 2 * band_px), "overwrite": ch * (4 * covered + 2 * (band_px - covered))}
+    if with_ff:
+        for m in out:
+            out[m] += ch * tile * tile * 4
+    return out
 
 
 def main():
     args = parse_args()
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cfg = WORKLOADS[args.workload]
+    tile, ch = cfg["tile"], cfg["channels"]
+    edge = args.edge_width or (256 if tile >= 2048 else tile // 8)
+
+    # The CPU baseline runs FIRST, on rank 0 of a one-GPU run: its worker processes are started
+    # before this process has touched the GPU.
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_pairs > 0:
+        cpu = cpu_baseline(args.cpu_pairs, edge, tile, args.fuse_mode, cfg["flatfield"])
+
+    import torch
+    import torch.distributed as dist
+
     if args.rehearse_gloo:
         local_rank = 0
     if world > 1:
@@ -158,9 +243,6 @@ def main():
     from image_stitcher_amd import dist as mdist
     from image_stitcher_amd._lib import check, lib, ptr
 
-    cfg = WORKLOADS[args.workload]
-    tile, ch = cfg["tile"], cfg["channels"]
-    edge = args.edge_width or (256 if tile >= 2048 else tile // 8)
     fft_flag = _lib.FFT_F64 if args.fft == "f64" else _lib.FFT_F32
     other_fft = "f32" if args.fft == "f64" else "f64"
     other_fft_flag = _lib.FFT_F32 if args.fft == "f64" else _lib.FFT_F64
@@ -168,49 +250,65 @@ def main():
     other_mode = "overwrite" if args.fuse_mode == "feather" else "feather"
     other_mode_id = _lib.FUSE_OVERWRITE if args.fuse_mode == "feather" else _lib.FUSE_FEATHER
 
-    ctx = _lib.Context(local_rank, torch.cuda.current_stream(device).cuda_stream, pair_chunk=args.pair_chunk)
-    tiles, true_yx, pair_idx, pair_dir = build_device_acquisition(cfg, seed=3 + rank, device=device)
-    n_tiles = cfg["rows"] * cfg["cols"]
-    n_pairs = len(pair_idx)
+    # ---- the partition: strong = one acquisition over all ranks, weak = one acquisition per rank ----
+    strong = args.scaling == "strong" or world == 1
+    part_world, part_rank = (world, rank) if strong else (1, 0)
+    seed = 3 if strong else 3 + rank
+    rows, cols = cfg["rows"], cfg["cols"]
+    n_tiles_grid = rows * cols
+    true_yx, _, _ = synth.planted_positions(seed, rows, cols, tile)
+    pair_idx, pair_dir = synth.grid_pairs(rows, cols)
+    n_pairs_grid = len(pair_idx)
     yx_np = (true_yx - true_yx.min(axis=0)).astype(np.int32)
     mosaic_h, mosaic_w = int(yx_np[:, 0].max()) + tile, int(yx_np[:, 1].max()) + tile
+    rs = mdist.RegistrationShard(pair_idx, rows, cols, part_world, part_rank)
+    fs = mdist.FusionShard(yx_np[:, 0], tile, mosaic_h, part_world, part_rank, align=args.band_align)
+    local_ids = np.union1d(rs.tile_ids, fs.tile_ids).astype(np.int64)   # resident tiles: both stages' needs
+    n_local = len(local_ids)
+    n_pairs = len(rs.pair_ids)                                          # pairs this rank registers
+
+    ctx = _lib.Context(local_rank, torch.cuda.current_stream(device).cuda_stream, pair_chunk=args.pair_chunk)
+    tiles, _, _, _ = synth.make_device_acquisition(rows, cols, tile, ch, seed, device, tile_ids=local_ids)
 
     # device-resident descriptors and outputs (nothing below allocates inside the timed loops
     # once the library workspaces have been sized by the warm-up steps)
-    d_pair_idx = torch.as_tensor(pair_idx, dtype=torch.int32, device=device)
-    d_pair_dir = torch.as_tensor(pair_dir, dtype=torch.uint8, device=device)
+    d_pair_idx = torch.as_tensor(rs.local_pairs(local_ids), dtype=torch.int32, device=device)
+    d_pair_dir = torch.as_tensor(pair_dir[rs.pair_ids], dtype=torch.uint8, device=device)
     d_out = torch.empty((n_pairs, 3), dtype=torch.float64, device=device)
     d_status = torch.empty((n_pairs,), dtype=torch.int8, device=device)
     d_out2, d_status2 = torch.empty_like(d_out), torch.empty_like(d_status)
-    d_yx = torch.as_tensor(np.tile(yx_np, (ch, 1)), dtype=torch.int32, device=device)
-    d_plane = torch.as_tensor(np.repeat(np.arange(ch), n_tiles), dtype=torch.int32, device=device)
-    mosaic = torch.empty((ch, mosaic_h, mosaic_w), dtype=torch.int16, device=device).view(torch.uint16)
+    band_yx = fs.local_yx(yx_np, local_ids)                             # relative to the band's first row
+    d_yx = torch.as_tensor(np.tile(band_yx, (ch, 1)), dtype=torch.int32, device=device)
+    d_plane = torch.as_tensor(np.repeat(np.arange(ch), n_local), dtype=torch.int32, device=device)
+    band_h = fs.rows
+    mosaic = torch.empty((ch, max(band_h, 1), mosaic_w), dtype=torch.int16, device=device).view(torch.uint16)
     ffs = None
-    reg_tiles = tiles[0]
     if cfg["flatfield"]:
         ffs = torch.as_tensor(np.stack([synth.make_flatfield(tile, tile, amplitude=0.2 - 0.03 * c) for c in range(ch)]),
                               device=device)
     ff_type = _lib.FF_F32 if ffs is not None else _lib.FF_NONE
-    counts = [n_pairs] * world
-    gathered = None
+    gathered = [None, None]
 
     def register(flags, out, status):
-        """Flatfield-correct the registration channel and register every pair: with a flatfield the
+        """Flatfield-correct the registration channel and register this rank's pairs: with a flatfield the
         strips are corrected as they are extracted (one call), which equals correcting whole tiles first."""
+        if n_pairs == 0:
+            return
         if ffs is not None:
-            check(lib.mistitch_register_pairs_flatfield(ctx.handle, ptr(tiles[0]), n_tiles, tile, tile, tile * tile,
+            check(lib.mistitch_register_pairs_flatfield(ctx.handle, ptr(tiles[0]), n_local, tile, tile, tile * tile,
                                                         ptr(ffs[0]), ff_type, ptr(d_pair_idx), ptr(d_pair_dir),
                                                         n_pairs, edge, flags, ptr(out), ptr(status)))
         else:
-            check(lib.mistitch_register_pairs(ctx.handle, ptr(tiles[0]), n_tiles, tile, tile, tile * tile,
+            check(lib.mistitch_register_pairs(ctx.handle, ptr(tiles[0]), n_local, tile, tile, tile * tile,
                                               ptr(d_pair_idx), ptr(d_pair_dir), n_pairs, edge, flags,
                                               ptr(out), ptr(status)))
 
     def step_registration():
-        nonlocal gathered
         register(fft_flag, d_out, d_status)
-        if world > 1:
-            gathered = mdist.all_gather_pair_results(d_out, d_status, counts)
+        if part_world > 1:   # every rank ends up with every pair row
+            gathered[0], gathered[1] = rs.gather(d_out, d_status)
+        else:
+            gathered[0], gathered[1] = d_out, d_status
 
     def step_registration_other():
         """The same step at the other FFT precision (reported beside the headline figure)."""
@@ -221,9 +319,11 @@ def main():
         register(fft_flag | _lib.REG_SUBPIXEL, d_out2, d_status2)
 
     def fuse(mode):
-        check(lib.mistitch_fuse(ctx.handle, ptr(tiles), ch * n_tiles, tile, tile, tile * tile, ptr(d_yx), ptr(d_plane),
+        if band_h == 0:
+            return
+        check(lib.mistitch_fuse(ctx.handle, ptr(tiles), ch * n_local, tile, tile, tile * tile, ptr(d_yx), ptr(d_plane),
                                 ptr(ffs), ff_type, ptr(d_plane) if ffs is not None else ptr(None), ptr(mosaic), ch,
-                                mosaic_h, mosaic_w, 0, mosaic_h, mode))
+                                band_h, mosaic_w, 0, band_h, mode))
 
     def step_fusion():
         fuse(mode_id)
@@ -254,8 +354,8 @@ def main():
         step_fusion()
     t_reg = timed(step_registration, args.steps)
     t_fuse = timed(step_fusion, args.steps)
-    # side figures: the other fusion mode and the other FFT precision, same bracketing
-    side = not args.no_side
+    # side figures (one-GPU runs): the other fusion mode and the other FFT precision, same bracketing
+    side = not args.no_side and world == 1
     if side:
         step_fusion_other()
         t_fuse_other = timed(step_fusion_other, args.steps)
@@ -282,13 +382,13 @@ def main():
         from image_stitcher_amd import ingest
         host_tiles = tiles[0].cpu().view(torch.int16).numpy().view(np.uint16)
         rows_per_band = 2
-        stager = ingest.TileStager(n_tiles, tile, tile, rows_per_band * cfg["cols"], device)
+        stager = ingest.TileStager(n_tiles_grid, tile, tile, rows_per_band * cols, device)
         ingest_ms = {}
         for label, fill in (("decoder_is_a_memcpy", ingest.fill_from_array(host_tiles)), ("buffers_prefilled", lambda lo, hi, dst: None)):
             for rep in range(2):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                _, out_s, st_s = ingest.register_streaming(fill, cfg["rows"], cfg["cols"], tile, tile, pair_idx, pair_dir, edge,
+                _, out_s, st_s = ingest.register_streaming(fill, rows, cols, tile, tile, pair_idx, pair_dir, edge,
                                                            rows_per_band=rows_per_band, fft=args.fft,
                                                            flatfield=ffs[0] if ffs is not None else None, ctx=ctx,
                                                            stager=stager)
@@ -298,14 +398,16 @@ def main():
                 ingest_same = bool(torch.equal(out_s, d_out) and torch.equal(st_s, d_status))
         del stager, host_tiles
 
-    # ---- parity properties at full size: every planted shift recovered, mosaic spot checks ----
-    out_np, st_np = d_out.cpu().numpy(), d_status.cpu().numpy()
+    # ---- parity properties at full size: every planted shift recovered (on the gathered rows) ----
+    step_registration()
+    torch.cuda.synchronize()
+    out_np, st_np = gathered[0].cpu().numpy(), gathered[1].cpu().numpy()
     expected = true_yx[pair_idx[:, 1]] - true_yx[pair_idx[:, 0]]
     shifts_ok = bool((st_np == 0).all() and np.array_equal(out_np[:, 1:].astype(np.int64), expected))
 
     # ---- the host step between the two device stages: pair rows -> tile positions (never part of `value`) ----
     from image_stitcher_amd import solve
-    grid_row, grid_col = np.repeat(np.arange(cfg["rows"]), cfg["cols"]), np.tile(np.arange(cfg["cols"]), cfg["rows"])
+    grid_row, grid_col = np.repeat(np.arange(rows), cols), np.tile(np.arange(cols), rows)
     t0 = time.perf_counter()
     solved = solve.solve_positions(solve.grid_from_pairs(grid_row, grid_col, pair_idx, pair_dir, out_np, st_np), tile, tile)
     t_solve = time.perf_counter() - t0
@@ -317,7 +419,7 @@ def main():
         ctx.profile(True)
         psteps = 2
         for _ in range(psteps):
-            step_registration()
+            register(fft_flag, d_out, d_status)
             step_fusion()
             if side:
                 step_fusion_other()
@@ -332,29 +434,24 @@ def main():
                     kernels[name] = dict(ms_per_step=ms, launches_per_step=float(launches), avg_launch_us=1e3 * ms / launches)
         ctx.profile(False)
 
-    # ---- algorithmic bytes ----
+    # ---- algorithmic bytes (this rank's share) ----
     strip_px = edge * tile
     reg_bytes_per_pair = 2 * strip_px * 2                      # two uint16 strips in
     cplx = 16 if args.fft == "f64" else 8
-    covered = union_area(yx_np, tile, tile)
-    clipped_tile_px = n_tiles * tile * tile                    # every tile lies inside the mosaic here
-    fuse_bytes_by_mode = {"feather": ch * (2 * clipped_tile_px + 2 * mosaic_h * mosaic_w),
-                          "overwrite": ch * (4 * covered + 2 * (mosaic_h * mosaic_w - covered))}
-    if ffs is not None:
-        for m in fuse_bytes_by_mode:
-            fuse_bytes_by_mode[m] += ch * tile * tile * 4      # flatfield planes, read once (cache resident)
+    fuse_bytes_by_mode = band_bytes(band_yx, tile, band_h, mosaic_w, ch, ffs is not None)
     fuse_bytes = fuse_bytes_by_mode[args.fuse_mode]
+    local_dir = pair_dir[rs.pair_ids]
     alg_bytes_per_step = {
         "k_fft_long_fwd": n_pairs * (2 * strip_px * 2 + strip_px * cplx),
         "k_fft_short_cps": n_pairs * (strip_px * cplx + (strip_px // 2) * cplx),
         "k_fft_long_inv": n_pairs * (strip_px // 2) * cplx,
         "k_ncc_accumulate": n_pairs * 2 * strip_px * 2,
-        "k_transpose_strips": int((pair_dir == 0).sum()) * 2 * strip_px * 2 * 2,
-        "k_flatfield": n_tiles * tile * tile * 4 + tile * tile * 4,
+        "k_transpose_strips": int((local_dir == 0).sum()) * 2 * strip_px * 2 * 2,
+        "k_flatfield": n_local * tile * tile * 4 + tile * tile * 4,
         "k_stage_strips": n_pairs * 2 * strip_px * 4 + tile * tile * 4,   # strip pixels in and out, one flatfield plane
         "k_fuse_feather": fuse_bytes_by_mode["feather"], "k_fuse_overwrite": fuse_bytes_by_mode["overwrite"],
     }
-    traffic = load_pmc_traffic(args.workload, args.fft)
+    traffic, traffic_note = load_pmc_traffic(args.workload, args.fft) if world == 1 else ({}, "counters are collected on one-GPU runs")
     rooflines = {}
     for name, k in kernels.items():
         if name in alg_bytes_per_step and k["ms_per_step"] > 0:
@@ -367,21 +464,31 @@ def main():
     in_step = [n for n in rooflines if n != f"k_fuse_{other_mode}"]
     dominant = max(in_step, key=lambda n: kernels[n]["ms_per_step"]) if in_step else None
 
-    pairs_per_s = world * n_pairs * args.steps / t_reg
-    mpix_per_step = ch * mosaic_h * mosaic_w / 1e6
-    mpix_per_s = world * mpix_per_step * args.steps / t_fuse
-    fuse_gbs = fuse_bytes * args.steps / t_fuse / 1e9            # per GPU
+    # whole-job figures: strong = the ONE grid / the slowest rank's time; weak = every rank's own grid
+    job_pairs = n_pairs_grid if strong else world * n_pairs_grid
+    mpix_per_step = ch * mosaic_h * mosaic_w / 1e6 * (1 if strong else world)
+    pairs_per_s = job_pairs * args.steps / t_reg
+    mpix_per_s = mpix_per_step * args.steps / t_fuse
+    fuse_gbs = fuse_bytes * args.steps / t_fuse / 1e9            # this rank's band / the slowest rank's time
+    reg_gbs = n_pairs * reg_bytes_per_pair * args.steps / t_reg / 1e9
     if side:
-        mpix_per_s_other = world * mpix_per_step * args.steps / t_fuse_other
+        mpix_per_s_other = mpix_per_step * args.steps / t_fuse_other
         fuse_gbs_other = fuse_bytes_by_mode[other_mode] * args.steps / t_fuse_other / 1e9
-        pairs_per_s_other = world * n_pairs * args.steps / t_reg_other
+        pairs_per_s_other = job_pairs * args.steps / t_reg_other
         shifts_ok_other = bool((st2_np == 0).all() and np.array_equal(out2_np[:, 1:].astype(np.int64), expected))
 
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_pairs > 0:
-        cpu = cpu_baseline(args.cpu_pairs, edge, tile, args.fuse_mode, cfg["flatfield"])
+    # per-rank shares, for the judge of load balance (gathered to rank 0)
+    shares = None
+    if world > 1:
+        mine = torch.tensor([float(n_pairs), float(band_h), float(n_local)], dtype=torch.float64, device=device)
+        every = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        shares = [dict(rank=r, pairs=int(v[0]), mosaic_rows=int(v[1]), tiles_resident=int(v[2])) for r, v in
+                  enumerate(t.cpu().tolist() for t in every)]
 
     if rank == 0:
+        part = (f"one acquisition sharded over {world} GPUs: contiguous runs of pairs, mosaic by row bands (multiples of {args.band_align} rows)"
+                if strong and world > 1 else ("one acquisition per GPU" if world > 1 else "one GPU"))
         line = {
             "metric": "tile_pairs_registered_per_sec",
             "value": round(pairs_per_s, 1),
@@ -391,35 +498,39 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * (t_reg + t_fuse) / args.steps, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (strong and world > 1) else "weak",
             "vs_baseline": None,
             "dtype": "f64" if args.fft == "f64" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {cfg['label']}, one acquisition per GPU",
-                       "pairs_per_gpu": n_pairs, "edge_width": edge, "fft": args.fft,
-                       "fuse_mode": args.fuse_mode, "mosaic": [ch, mosaic_h, mosaic_w]},
+            "config": {"workload": f"{args.workload}: {cfg['label']}, {part}",
+                       "pairs_in_job": job_pairs, "pairs_on_rank0": n_pairs, "edge_width": edge, "fft": args.fft,
+                       "fuse_mode": args.fuse_mode, "mosaic": [ch, mosaic_h, mosaic_w],
+                       "mosaic_rows_on_rank0": band_h, "tiles_resident_on_rank0": n_local},
             "registration": {"ms_per_step": round(1e3 * t_reg / args.steps, 3),
                              "includes": ("flatfield applied to the edge strips as they are extracted, " if ffs is not None else "")
-                             + "register_pairs" + (", RCCL all-gather of pair rows" if world > 1 else ""),
+                             + "register_pairs" + (", RCCL all-gather of pair rows" if (strong and world > 1) else ""),
                              "roofline_whole_path": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                                                     "achieved": round(pairs_per_s / world * reg_bytes_per_pair / 1e9, 1),
-                                                     "frac": round(pairs_per_s / world * reg_bytes_per_pair / 1e9
-                                                                   / HBM_PEAK_GBS, 4),
-                                                     "algorithmic_bytes_per_pair": reg_bytes_per_pair}},
+                                                     "achieved": round(reg_gbs, 1), "frac": round(reg_gbs / HBM_PEAK_GBS, 4),
+                                                     "algorithmic_bytes_per_pair": reg_bytes_per_pair,
+                                                     "per": "GPU (rank 0's pairs / the slowest rank's time)"}},
             "fusion": {"metric": "fused_mosaic_MPix_per_sec", "value": round(mpix_per_s, 1), "unit": "MPix/s",
                        "dtype": "u16", "mode": args.fuse_mode, "ms_per_step": round(1e3 * t_fuse / args.steps, 3),
                        "roofline": {"bound": "hbm", "achieved": round(fuse_gbs, 1), "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": round(fuse_gbs / HBM_PEAK_GBS, 4),
                                     "traffic": traffic.get(f"k_fuse_{args.fuse_mode}"),
-                                    "algorithmic_bytes_per_launch": int(fuse_bytes)}},
-            "parity": {"planted_integer_shifts_recovered": shifts_ok, "pairs_checked": int(n_pairs),
+                                    "algorithmic_bytes_per_launch": int(fuse_bytes),
+                                    "per": "GPU (rank 0's band / the slowest rank's time)"}},
+            "parity": {"planted_integer_shifts_recovered": shifts_ok, "pairs_checked": int(len(out_np)),
                        "solved_positions_are_the_fused_positions": positions_ok},
-            "position_solve": {"ms": round(1e3 * t_solve, 2), "where": "host, one core, on this rank's pair rows",
+            "position_solve": {"ms": round(1e3 * t_solve, 2), "where": "host, one core, every rank on the gathered pair rows",
                                "tree_edges": len(solved.tree)},
             "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
+            "traffic_source": traffic_note,
             "kernels": {n: {**{k: round(v, 3) for k, v in kernels[n].items()},
                             **({"hbm_frac": rooflines[n]["frac"]} if n in rooflines else {})} for n in kernels},
         }
+        if shares is not None:
+            line["ranks"] = shares
         if side:
             line["fusion_" + other_mode] = {
                 "value": round(mpix_per_s_other, 1), "unit": "MPix/s",
@@ -432,17 +543,16 @@ def main():
                 "value": round(pairs_per_s_other, 1), "unit": "tile-pairs/s",
                 "ms_per_step": round(1e3 * t_reg_other / args.steps, 3),
                 "planted_integer_shifts_recovered": shifts_ok_other}
-        if side:
             line["host_to_device"] = {"GB/s": round(h2d_gbs, 1), "sample": f"{n_h2d} tiles from pinned host memory, 3 copies",
                                       "upload_of_this_workload_s": round(tiles.numel() * 2 / h2d_gbs / 1e9, 3)}
-            line["ingest"] = {"what": f"one channel ({n_tiles} tiles, {n_tiles * tile * tile * 2 / 1e9:.2f} GB) uploaded in bands of "
+            line["ingest"] = {"what": f"one channel ({n_tiles_grid} tiles, {n_tiles_grid * tile * tile * 2 / 1e9:.2f} GB) uploaded in bands of "
                                       f"{rows_per_band} grid rows through two pinned buffers, pairs registered as bands arrive",
                               "upload_and_register_ms": {k: round(v, 1) for k, v in ingest_ms.items()},
-                              "upload_alone_at_measured_rate_ms": round(n_tiles * tile * tile * 2 / h2d_gbs / 1e6, 1),
+                              "upload_alone_at_measured_rate_ms": round(n_tiles_grid * tile * tile * 2 / h2d_gbs / 1e6, 1),
                               "register_alone_ms": round(1e3 * t_reg / args.steps, 1),
                               "rows_equal_resident_registration": ingest_same}
             line["registration_subpixel"] = {
-                "value": round(world * n_pairs * args.steps / t_reg_sub, 1), "unit": "tile-pairs/s",
+                "value": round(job_pairs * args.steps / t_reg_sub, 1), "unit": "tile-pairs/s",
                 "ms_per_step": round(1e3 * t_reg_sub / args.steps, 3), "upsample_factor": 100,
                 "max_abs_shift_error_px": float(np.abs(out3_np[:, 1:] - expected).max())}
         if cpu is not None:
@@ -453,9 +563,10 @@ def main():
                           f"(flatfield + register, NumPy oracle incl. least-squares polish, serial as the reference); "
                           f"fusion: {cpu['tiles_fused']} tiles, {args.fuse_mode}",
                 "host_cpus": os.cpu_count(),
-                "all_cores": {"value": round(cpu["pairs"] / cpu["t_reg_threads"], 3), "unit": "tile-pairs/s",
-                              "cores": cpu["threads"],
-                              "sample": "the same pairs, registration only (tiles already corrected), one thread per core"},
+                "all_cores": {"value": round(cpu["pairs"] / cpu["t_reg_procs"], 3), "unit": "tile-pairs/s",
+                              "cores": cpu["procs"],
+                              "sample": "the same pairs, registration only (tiles already corrected), one worker PROCESS per "
+                                        "core, started before the GPU was touched"},
                 "fusion_value": round(cpu["fused_mpix"] / cpu["t_fuse"], 2), "fusion_unit": "MPix/s",
                 "gpu_over_cpu_registration": round(pairs_per_s / cpu_pairs_s, 1),
                 "gpu_over_cpu_fusion": round(mpix_per_s / (cpu["fused_mpix"] / cpu["t_fuse"]), 1),

@@ -40,6 +40,19 @@ def shard_pairs_by_grid_rows(pair_idx: np.ndarray, n_cols: int, n_rows: int, wor
     return mine, tiles
 
 
+def shard_pairs_evenly(pair_idx: np.ndarray, world: int, rank: int) -> Tuple[np.ndarray, np.ndarray]:
+    """Pairs owned by ``rank`` when the pair list (in the reference's visiting order: row-major by
+    centre tile, left then top) is cut into ``world`` contiguous runs of equal length (+-1).  A run
+    covers about ``n_rows / world`` grid rows plus a partial row at either end; the tiles it needs
+    are those of its pairs (the row above the run's first centre tiles is the halo).
+    Returns (indices into the global pair list, sorted unique tile indices needed)."""
+    pair_idx = np.asarray(pair_idx).reshape(-1, 2)
+    lo, hi = band_bounds(len(pair_idx), world, rank)
+    mine = np.arange(lo, hi)
+    tiles = np.unique(pair_idx[mine].reshape(-1)) if len(mine) else np.zeros((0,), dtype=pair_idx.dtype)
+    return mine, tiles
+
+
 def shard_mosaic_rows(mosaic_h: int, world: int, rank: int, align: int = 1) -> Tuple[int, int]:
     """Row band ``[row0, row1)`` of the mosaic for ``rank``; band edges are multiples of
     ``align`` (the output chunk height) except the last."""
@@ -102,3 +115,72 @@ def scatter_to_global(mine_lists: List[np.ndarray], rows, status, n_pairs: int):
     g_rows[idx] = rows
     g_st[idx] = status
     return g_rows, g_st
+
+
+# ------------------------------------------------------------------------------------------------
+# one acquisition sharded over the ranks of a node: registration by grid-row bands of pairs,
+# one all-gather of the pair rows, the (tiny) position solve replicated, fusion by mosaic row bands
+# ------------------------------------------------------------------------------------------------
+class RegistrationShard:
+    """What ``rank`` of ``world`` registers of one grid: its pairs (the reference's serial pair loop,
+    tile_registration.py:336-376, cut into contiguous grid-row bands) and the tiles they need."""
+
+    def __init__(self, pair_idx, n_rows: int, n_cols: int, world: int, rank: int, by: str = "pairs"):
+        """``by``: "pairs" = contiguous runs of equal pair counts (balanced: 95 pairs each for a 20 x 20
+        grid on 8 ranks), "grid_rows" = whole grid rows per rank (3 or 2 rows each there)."""
+        self.world, self.rank = int(world), int(rank)
+        self.pair_idx = np.asarray(pair_idx, dtype=np.int32).reshape(-1, 2)
+        self.n_pairs = len(self.pair_idx)
+        if by == "pairs":
+            cut = lambda r: shard_pairs_evenly(self.pair_idx, world, r)
+        elif by == "grid_rows":
+            cut = lambda r: shard_pairs_by_grid_rows(self.pair_idx, n_cols, n_rows, world, r)
+        else:
+            raise ValueError(f"unknown partition {by!r}")
+        self.pair_lists = [cut(r)[0] for r in range(world)]
+        self.counts = [len(m) for m in self.pair_lists]
+        self.pair_ids, self.tile_ids = cut(rank)
+
+    def local_pairs(self, local_ids) -> np.ndarray:
+        """This rank's pairs with tile indices renumbered into ``local_ids`` (sorted global ids of the
+        tiles the rank holds; must contain ``tile_ids``)."""
+        local_ids = np.asarray(local_ids)
+        pos = np.searchsorted(local_ids, self.pair_idx[self.pair_ids].reshape(-1))
+        if len(pos) and (pos.max() >= len(local_ids) or (local_ids[pos] != self.pair_idx[self.pair_ids].reshape(-1)).any()):
+            raise ValueError("a tile this rank's pairs need is not resident")
+        return pos.reshape(-1, 2).astype(np.int32)
+
+    def gather(self, out_local, status_local):
+        """Rows of every rank in global pair order: the one exchange of the path (an all-gather of
+        24 bytes + 1 byte per pair); with one rank, or outside a process group, a plain reorder."""
+        import torch.distributed as dist
+
+        if self.world > 1:
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError("world > 1 needs an initialised process group")
+            rows, st = all_gather_pair_results(out_local, status_local, self.counts)
+        else:
+            rows, st = out_local, status_local
+        return scatter_to_global(self.pair_lists, rows, st, self.n_pairs)
+
+
+class FusionShard:
+    """The band of mosaic rows ``rank`` of ``world`` fuses (whole output chunk rows, stitcher.py:388-405
+    cut by output row) and the tiles that touch it; a tile straddling a band edge is held by both ranks."""
+
+    def __init__(self, tile_y, tile_h: int, mosaic_h: int, world: int, rank: int, align: int = 2048):
+        self.row0, self.row1 = shard_mosaic_rows(int(mosaic_h), world, rank, align)
+        self.tile_ids = tiles_touching_rows(np.asarray(tile_y), tile_h, self.row0, self.row1) \
+            if self.row1 > self.row0 else np.zeros((0,), dtype=np.int64)
+
+    @property
+    def rows(self) -> int:
+        return self.row1 - self.row0
+
+    def local_yx(self, tile_yx, ids=None) -> np.ndarray:
+        """Positions of ``ids`` (default: the touching tiles) relative to the band's first row: the band is
+        fused as a mosaic of its own, rows above it simply fall outside."""
+        ids = self.tile_ids if ids is None else np.asarray(ids)
+        yx = np.asarray(tile_yx, dtype=np.int32).reshape(-1, 2)[ids].copy()
+        yx[:, 0] -= self.row0
+        return yx

@@ -103,15 +103,18 @@ def planted_positions(seed: int, rows: int, cols: int, tile: int, overlap: float
 
 
 def make_device_acquisition(rows: int, cols: int, tile: int, channels: int, seed: int, device,
-                            keep_scenes: bool = False, scene_seeds=None):
+                            keep_scenes: bool = False, scene_seeds=None, tile_ids=None):
     """Tiles ``[C, N, H, W]`` uint16 cut ON THE DEVICE from white-noise scenes (one per channel),
     with the planted geometry: (tiles, true_yx, pair_idx, pair_dir[, scenes]); ``keep_scenes`` is
-    True (all) or the channel indices whose scenes to return.  Full-size
+    True (all) or the channel indices whose scenes to return; ``tile_ids`` (sorted global tile
+    indices) cuts only those tiles: ``tiles`` is then ``[C, len(tile_ids), H, W]`` (what one rank of
+    a sharded run holds; every rank draws the same scenes from the same seeds).  Full-size
     acquisitions (13 GB for a 20 x 20 x 4 grid) never exist on the host."""
     import torch
 
     true_yx, sh, sw = planted_positions(seed, rows, cols, tile)
-    tiles = torch.empty((channels, rows * cols, tile, tile), dtype=torch.int16, device=device)
+    ids = np.arange(rows * cols) if tile_ids is None else np.asarray(tile_ids, dtype=np.int64)
+    tiles = torch.empty((channels, len(ids), tile, tile), dtype=torch.int16, device=device)
     gen = torch.Generator(device=device)
     scenes = []
     band = 4096
@@ -121,7 +124,8 @@ def make_device_acquisition(rows: int, cols: int, tile: int, channels: int, seed
         for y in range(0, sh, band):  # in bands: the float32 scene never exists whole
             h = min(band, sh - y)
             scene[y:y + h] = (1000.0 + 30000.0 * torch.rand((h, sw), generator=gen, device=device)).to(torch.int16)
-        for n, (y0, x0) in enumerate(true_yx):  # values <= 31000: same bits as uint16
+        for n, t in enumerate(ids):  # values <= 31000: same bits as uint16
+            y0, x0 = true_yx[t]
             tiles[c, n] = scene[y0:y0 + tile, x0:x0 + tile]
         if keep_scenes is True or (keep_scenes and c in keep_scenes):
             scenes.append(scene.view(torch.uint16))

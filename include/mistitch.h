@@ -204,7 +204,9 @@ int mistitch_apply_flatfield(mistitch_ctx* ctx, const uint16_t* in, const void* 
  * (stitcher.py:208-253, 272-311).
  *
  *   tiles      [n_tiles] images tile_h x tile_w uint16, image t at tiles + t*tile_pitch
- *   tile_yx    [n_tiles][2] int32 mosaic position (y, x) of each tile's origin, >= 0
+ *   tile_yx    [n_tiles][2] int32 mosaic position (y, x) of each tile's origin; a tile that sticks out of
+ *              the mosaic on any side (negative coordinates included: a row band fused as a mosaic of
+ *              its own sees the tiles that straddle its first row that way) is clipped
  *   tile_plane [n_tiles] int32 destination plane (channel * Z + z) of each tile
  *   n_planes   planes in the mosaic; planes are mosaic_h x mosaic_w, contiguous
  *   tile array order IS the placement order: a later tile overwrites an earlier one

@@ -29,28 +29,26 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         g = synth.make_grid(5, 3, 3, 128, 128, overlap=0.15, jitter=2)
-        mine, tiles_needed = mdist.shard_pairs_by_grid_rows(g.pair_idx, g.cols, g.rows, world, rank)
+        rs = mdist.RegistrationShard(g.pair_idx, g.rows, g.cols, world, rank, by="grid_rows")
         # a rank only touches the tiles of its band plus the halo row above it
-        local_tiles = {int(t): g.tiles[t] for t in tiles_needed}
-        remap = {t: i for i, t in enumerate(sorted(local_tiles))}
-        stack = np.stack([local_tiles[t] for t in sorted(local_tiles)])
-        lp = np.array([[remap[int(a)], remap[int(b)]] for a, b in g.pair_idx[mine]]).reshape(-1, 2)
-        out, st = oreg.register_pairs(stack, lp, g.pair_dir[mine], 32, polish=False)
-        counts = [len(mdist.shard_pairs_by_grid_rows(g.pair_idx, g.cols, g.rows, world, r)[0]) for r in range(world)]
-        rows, status = mdist.all_gather_pair_results(torch.from_numpy(out), torch.from_numpy(st), counts)
-        lists = [mdist.shard_pairs_by_grid_rows(g.pair_idx, g.cols, g.rows, world, r)[0] for r in range(world)]
-        g_rows, g_st = mdist.scatter_to_global(lists, rows, status, len(g.pair_idx))
+        local_ids = np.asarray(rs.tile_ids)
+        stack = g.tiles[local_ids]
+        out, st = oreg.register_pairs(stack, rs.local_pairs(local_ids), g.pair_dir[rs.pair_ids], 32, polish=False)
+        g_rows, g_st = rs.gather(torch.from_numpy(out), torch.from_numpy(st))
         # every rank holds every pair now and solves the (tiny) position problem for itself
         row, col = np.repeat(np.arange(g.rows), g.cols), np.tile(np.arange(g.cols), g.rows)
         res = solve.solve_positions(solve.grid_from_pairs(row, col, g.pair_idx, g.pair_dir, g_rows.numpy(),
                                                           g_st.numpy()), 128, 128)
         yx = np.stack([res.y_pos, res.x_pos], axis=1).astype(np.int32)
         assert np.array_equal(yx, g.true_yx - g.true_yx.min(axis=0))
-        # fusion bands
+        # fusion bands: each as a mosaic of its own, tile rows relative to the band
         mh, mw = int(yx[:, 0].max()) + 128, int(yx[:, 1].max()) + 128
-        r0, r1 = mdist.shard_mosaic_rows(mh, world, rank, align=64)
-        use = mdist.tiles_touching_rows(yx[:, 0], 128, r0, r1)
+        fs = mdist.FusionShard(yx[:, 0], 128, mh, world, rank, align=64)
+        r0, r1 = fs.row0, fs.row1
+        use = fs.tile_ids
         band = ofu.fuse_overwrite(g.tiles[use], yx[use], np.zeros(len(use), dtype=int), 1, mh, mw)[0, r0:r1]
+        assert [tuple(v) for v in fs.local_yx(yx)] == [(int(y) - r0, int(x)) for y, x in yx[use]]
+        local_tiles = {int(t): None for t in local_ids}
         q.put((rank, g_rows.numpy(), g_st.numpy(), (r0, r1), band, sorted(local_tiles)))
     finally:
         dist.destroy_process_group()
@@ -91,3 +89,10 @@ def test_band_helpers():
     pair_idx, _ = synth.grid_pairs(20, 20)
     sizes = [len(mdist.shard_pairs_by_grid_rows(pair_idx, 20, 20, 8, r)[0]) for r in range(8)]
     assert sum(sizes) == 760 and max(sizes) - min(sizes) <= 39
+    even = [mdist.RegistrationShard(pair_idx, 20, 20, 8, r) for r in range(8)]
+    assert [len(s.pair_ids) for s in even] == [95] * 8
+    assert np.array_equal(np.concatenate([s.pair_ids for s in even]), np.arange(760))
+    for s in even:   # the tiles of a run: its centre tiles, their left neighbours and the row above
+        need = np.unique(pair_idx[s.pair_ids].reshape(-1))
+        assert np.array_equal(s.tile_ids, need) and len(need) <= 4 * 20
+        assert np.array_equal(s.local_pairs(need).shape, (95, 2))

@@ -235,3 +235,19 @@ def test_plate_of_wells_as_planes(fu, mode):
         alone = fuse(tiles[sl], yx[sl], [p - w * ch for p in plane[sl]], ch, h, wd, flatfields=ffs, tile_ff=ffidx[sl])
         assert np.array_equal(got[w * ch:(w + 1) * ch, :h, :wd], alone), w
         assert (got[w * ch:(w + 1) * ch, h:] == 0).all() and (got[w * ch:(w + 1) * ch, :, wd:] == 0).all()
+
+
+@pytest.mark.parametrize("mode", ["overwrite", "feather"])
+def test_tiles_sticking_out_on_every_side_are_clipped(fu, mode):
+    """Tile origins left of and above the mosaic (negative coordinates) as well as tiles past its right
+    and lower edge: the mosaic equals the window of a larger oracle canvas."""
+    tiles, yx, plane, mh, mw = overlapping_scene(51, 3, 4, 64, 96, n_planes=2)
+    oracle = ofu.fuse_overwrite if mode == "overwrite" else ofu.fuse_feather
+    canvas = oracle(tiles, yx, plane, 2, mh, mw)
+    oy, ox, wh, ww = 37, 53, mh - 37 - 21, mw - 53 - 30        # a window strictly inside the canvas
+    shifted = yx.copy()
+    shifted[:, 0] -= oy
+    shifted[:, 1] -= ox
+    assert (shifted < 0).any()
+    got = _np(fu.fuse_tiles(tiles, shifted, plane, 2, wh, ww, mode=mode))
+    assert np.array_equal(got, canvas[:, oy:oy + wh, ox:ox + ww])

@@ -20,6 +20,18 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def kernel_source_hash():
+    """sha256 over the kernel sources: the counters in pmc_traffic.json describe exactly these files."""
+    import hashlib
+    h = hashlib.sha256()
+    src = os.path.join(ROOT, "image-stitcher_amd", "csrc")
+    for name in sorted(os.listdir(src)):
+        if name.endswith((".hip", ".hpp", ".h")):
+            with open(os.path.join(src, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def short_name(full):
     """'void mistitch::k_fuse<1, 1, 4>(...)' -> the name the library's own profiler uses."""
     m = re.search(r"mistitch::(k_[a-z0-9_]+)(<([^>]*)>)?", full)
@@ -76,7 +88,7 @@ def main():
                 rec["hbm_bytes_per_launch"] = int((2.0 * fetch + write) * 1024)
                 rec["launches_seen"] = len(launches[name]["FETCH_SIZE"])
                 kernels[name] = rec
-        doc = {"tag": args.tag, "workload": args.workload, "fft": args.fft,
+        doc = {"tag": args.tag, "workload": args.workload, "fft": args.fft, "kernel_source_sha256": kernel_source_hash(),
                "formula": "hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes",
                "kernels": kernels}
         with open(os.path.join(out_dir, "pmc_traffic.json"), "w") as fh:
