@@ -22,6 +22,7 @@ ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM = -1, -2, -3, -4
 PAIR_OK, PAIR_FEATURELESS, PAIR_NO_CANDIDATE = 0, 1, 2
 FFT_F64, FFT_F32 = 0, 1
 REG_SUBPIXEL = 2
+REG_PEAKS10 = 4
 FUSE_OVERWRITE, FUSE_FEATHER = 0, 1
 FF_NONE, FF_F32, FF_F64 = 0, 1, 2
 
@@ -32,7 +33,7 @@ EXPORTS = [
     "mistitch_apply_flatfield", "mistitch_fuse", "mistitch_mip", "mistitch_synchronize",
     "mistitch_profile_enable", "mistitch_profile_collect", "mistitch_subpixel_shift",
     "mistitch_set_upsample_factor", "mistitch_pyramid", "mistitch_refine_pairs",
-    "mistitch_register_pairs_flatfield", "mistitch_fuse_static",
+    "mistitch_register_pairs_flatfield", "mistitch_fuse_static", "mistitch_register_pairs_candidates",
 ]
 
 
@@ -59,6 +60,7 @@ def _load() -> C.CDLL:
         "mistitch_reserve_registration": [vp, i32, i32, i32, i32, u32],
         "mistitch_register_pairs": [vp, vp, i32, i32, i32, i64, vp, vp, i32, i32, u32, vp, vp],
         "mistitch_register_pairs_flatfield": [vp, vp, i32, i32, i32, i64, vp, i32, vp, vp, i32, i32, u32, vp, vp],
+        "mistitch_register_pairs_candidates": [vp, vp, i32, i32, i32, i64, vp, i32, vp, vp, i32, i32, u32, vp, vp, vp],
         "mistitch_refine_pairs": [vp, vp, i32, i32, i32, i64, vp, vp, i32, i32, vp, C.c_double, vp, vp],
         "mistitch_pcm": [vp, vp, i64, vp, i64, i32, i32, u32, vp],
         "mistitch_pcm_topk": [vp, vp, i64, vp, i64, i32, i32, u32, i32, vp, vp, vp],

@@ -44,9 +44,11 @@ __device__ unsigned long long g_stamps[3][4096][8];
 
 constexpr int kThreads = 256;
 constexpr int kMaxK = 16;       // peaks a block / a pair can report
-constexpr int kNumCand = 32;    // 2 peaks x 16 signed interpretations
+constexpr int kNumCand = 32;    // 2 peaks x 16 signed interpretations: the discrete search of the default path
+constexpr int kNumCandWide = 160;  // 10 peaks x 16: the candidate set of the reference's consensus stage (MISTITCH_REG_PEAKS10)
 constexpr int kNccChunks = 8;   // workgroups cooperating on one candidate
-constexpr int kCandSlots = kNumCand + 1;  // the last slot holds the subpixel estimate's rounded shift (flag 1 when unused)
+// A pair has n_cand + 1 candidate slots (n_cand = kNumCand or kNumCandWide, a kernel argument): the last slot
+// holds the subpixel estimate's rounded shift (flag 1 when unused).
 constexpr int kUpsMax = 160;    // largest upsampled region side (ceil(1.5 * upsample factor))
 constexpr int kUpsRows = 80;    // upsampled rows per block of the second stage (five 16-row tiles)
 
@@ -916,6 +918,22 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
     MS_STAMP(2, 3);
     return;
   }
+  if (partial_abs != nullptr) {  // largest magnitude, first in row-major order (subpixel stage only)
+    Peak ba{-INFINITY, -1, -1};
+    for (int e = tid; e < NF * L; e += kThreads) {
+      const int f = e >> lL, l = e & (L - 1);
+      const cx<T> v = buf[addr(f, l)];
+      const int s = s0 + 2 * f;
+      const int key0 = d.transposed ? l * S + s : s * L + l;
+      const int key1 = d.transposed ? key0 + 1 : key0 + L;
+      const double a0v = fabs((double)v.x * scale), a1v = fabs((double)v.y * scale);
+      if (s < S && first_better(a0v, key0, ba.val, ba.key)) ba = Peak{a0v, key0, 0};
+      if (s + 1 < S && first_better(a1v, key1, ba.val, ba.key)) ba = Peak{a1v, key1, 0};
+    }
+    const Peak best = block_argmax_first(ba, red);
+    if (tid == 0) partial_abs[(int64_t)blockIdx.y * abs_stride + blockIdx.x] = best;
+    __syncthreads();
+  }
   // k rounds of block argmax; a taken element is overwritten with -inf.
   for (int round = 0; round < k; ++round) {
     Peak mine{-INFINITY, -1, -1};
@@ -1302,8 +1320,8 @@ __global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* d
                                                                int pair0, Peak* partial, int partial_stride,
                                                                int nblk_direct, int nblk_transposed, int k,
                                                                int n_peaks_used, Peak* peaks /*[P][kMaxK]*/,
-                                                               Cand* cand /*[P][kCandSlots]*/,
-                                                               unsigned long long* acc /*[P][kCandSlots][5]*/) {
+                                                               Cand* cand /*[P][16 n_peaks_used + 1]*/,
+                                                               unsigned long long* acc /*[P][16 n_peaks_used + 1][5]*/) {
   __shared__ Peak red[kThreads / 64];
   __shared__ Peak top[kMaxK];
   const int p = pair0 + blockIdx.x;
@@ -1327,12 +1345,14 @@ __global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* d
     __syncthreads();
   }
   if (cand == nullptr) return;
-  if (tid == kNumCand) {  // the subpixel slot stays unused until k_ups_finish fills it
-    cand[(int64_t)p * kCandSlots + kNumCand] = Cand{0, 0, 1, -1};
-    for (int i = 0; i < 5; ++i) acc[((int64_t)p * kCandSlots + kNumCand) * 5 + i] = 0ull;
+  const int n_cand = 16 * n_peaks_used, slots = n_cand + 1;
+  static_assert(kNumCandWide < kThreads, "one thread per candidate and one for the subpixel slot");
+  if (tid == n_cand) {  // the subpixel slot stays unused until k_ups_finish fills it
+    cand[(int64_t)p * slots + n_cand] = Cand{0, 0, 1, -1};
+    for (int i = 0; i < 5; ++i) acc[((int64_t)p * slots + n_cand) * 5 + i] = 0ull;
   }
-  __shared__ Cand sc[kNumCand];
-  if (tid < kNumCand) {
+  __shared__ Cand sc[kNumCandWide];
+  if (tid < n_cand) {
     const int pk = tid >> 4, t = tid & 15;
     Cand c{0, 0, 1, -1};
     if (pk < n_peaks_used && pk < k && top[pk].key >= 0) {
@@ -1351,10 +1371,10 @@ __global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* d
       }
     }
     sc[tid] = c;
-    for (int i = 0; i < 5; ++i) acc[((int64_t)p * kCandSlots + tid) * 5 + i] = 0ull;
+    for (int i = 0; i < 5; ++i) acc[((int64_t)p * slots + tid) * 5 + i] = 0ull;
   }
   __syncthreads();
-  if (tid < kNumCand) {
+  if (tid < n_cand) {
     Cand c = sc[tid];
     if (c.flag == 0) {
       for (int e = 0; e < tid; ++e) {
@@ -1366,7 +1386,7 @@ __global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* d
         }
       }
     }
-    cand[(int64_t)p * kCandSlots + tid] = c;
+    cand[(int64_t)p * slots + tid] = c;
   }
 }
 
@@ -1819,7 +1839,7 @@ __global__ __launch_bounds__(kThreads) void k_ups_long(const PairDesc* desc, con
 
 // One thread per pair: the refined shift and its rounded position as the last candidate slot.
 __global__ void k_ups_finish(const PairDesc* desc, const int8_t* status, int pair0, int n, const Peak* partial_ups,
-                             int n_row_blocks, int n_up, double uf, UpsState* ups, Cand* cand) {
+                             int n_row_blocks, int n_up, double uf, UpsState* ups, Cand* cand, int n_cand) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int p = pair0 + i;
@@ -1852,7 +1872,7 @@ __global__ void k_ups_finish(const PairDesc* desc, const int8_t* status, int pai
     c.flag = 2;
   else
     c.flag = 0;
-  cand[(int64_t)p * kCandSlots + kNumCand] = c;
+  cand[(int64_t)p * (n_cand + 1) + n_cand] = c;
 }
 
 // Exact integer moments of two uint16 rows, 8 pixels per lane and step.  Pixels
@@ -2035,7 +2055,7 @@ __device__ __forceinline__ void reduce_moments(unsigned long long (&v)[5], unsig
 }
 
 // Exact moments (sum a, sum b, sum a^2, sum b^2, sum ab) over the overlap of a
-// candidate shift.  One-dimensional grid of 8 * ceil(pairs_in_pass / 8) * kCandSlots * kNccChunks
+// candidate shift.  One-dimensional grid of 8 * ceil(pairs_in_pass / 8) * (n_cand + 1) * kNccChunks
 // workgroups.  Workgroups go to the eight XCDs in turn, each with an L2 of its own, so
 // workgroup b works for pair (b mod 8) + 8 * (...): every candidate of a pair is then summed
 // on one XCD, whose L2 keeps that pair's two strips while its ~30 overlaps are read from them.
@@ -2043,10 +2063,11 @@ constexpr int kXcds = 8;
 constexpr int kShortStripRows = 256;  // the usual edge width: sizes the "small overlap" test below
 __global__ __launch_bounds__(kThreads, 8) void k_ncc_accumulate(const PairDesc* desc, const int8_t* status,
                                                              int pair0, int n_in_pass, const Cand* cand,
-                                                             unsigned long long* acc) {
+                                                             unsigned long long* acc, int n_cand) {
   __shared__ unsigned long long red[5 * kThreads / 64];
   const int xcd = blockIdx.x % kXcds, seq = blockIdx.x / kXcds;
-  constexpr int kPerPair = kNccChunks * kCandSlots;
+  const int slots = n_cand + 1;
+  const int kPerPair = kNccChunks * slots;
   const int pz = xcd + kXcds * (seq / kPerPair);
   if (pz >= n_in_pass) return;
   const int within = seq % kPerPair;
@@ -2054,7 +2075,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_ncc_accumulate(const PairDesc* 
   const int p = pair0 + pz;
   // three independent lookups, requested together ahead of the first test
   const int8_t st = status[p];
-  const Cand c = cand[(int64_t)p * kCandSlots + ci];
+  const Cand c = cand[(int64_t)p * slots + ci];
   const PairDesc d = desc[p];
   if (st != MISTITCH_PAIR_OK || c.flag != 0) return;
   const int ds = d.transposed ? c.x : c.y;
@@ -2073,7 +2094,7 @@ __global__ __launch_bounds__(kThreads, 8) void k_ncc_accumulate(const PairDesc* 
   unsigned long long v[5];
   moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, first, s_hi, step,
                   l_hi - l_lo, v);
-  reduce_moments(v, red, acc + ((int64_t)p * kCandSlots + ci) * 5);
+  reduce_moments(v, red, acc + ((int64_t)p * slots + ci) * 5);
 }
 
 // ---- exact 128-bit helpers -------------------------------------------------
@@ -2115,55 +2136,82 @@ __device__ double ncc_from_moments(unsigned long long n, unsigned long long sa, 
   return r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);
 }
 
-// One wave per pair: lane c scores candidate c, lane kNumCand the subpixel estimate; the winner is the
-// first candidate in evaluation order that no other beats (the serial walk's strict ">").
-static_assert(kNumCand < 64, "one lane per candidate plus one");
+// One wave per pair: the lanes score the candidates 64 at a time in evaluation order; the winner is the first
+// candidate that no other beats (the serial walk's strict ">").  The subpixel estimate, in the slot behind the
+// candidates, is listed BEFORE the two-peak discrete result by the reference and wins ties against it
+// (_translation_computation.py:1232-1313), but AFTER the consensus stage's result, which wins ties against it
+// (`wide`: the 160-candidate set of that stage is in use, :1197-1230).
+// `table` (optional): [n_pairs][n_cand][3] = y, x, ncc of every candidate in evaluation order, strip relative;
+// ncc NaN where the reference does not score the candidate (empty overlap).
 __global__ __launch_bounds__(256) void k_finalize(const PairDesc* desc, const int8_t* status_in, int n_pairs,
                                                   const Cand* cand, const unsigned long long* acc, double* out,
-                                                  int8_t* status, const UpsState* ups) {
+                                                  int8_t* status, const UpsState* ups, int n_cand, int wide,
+                                                  double* table) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (p >= n_pairs) return;
+  const double nan = __longlong_as_double(0x7ff8000000000000ll);
+  const int slots = n_cand + 1;
   if (status_in[p] != MISTITCH_PAIR_OK) {
-    const double nan = __longlong_as_double(0x7ff8000000000000ll);
     if (lane < 3) out[3 * p + lane] = nan;
+    if (table != nullptr)
+      for (int e = lane; e < 3 * n_cand; e += 64) table[(int64_t)p * n_cand * 3 + e] = nan;
     return;
   }
   const PairDesc d = desc[p];
-  const bool has_ups = ups != nullptr && ups[p].valid;
-  const bool mine = lane < kNumCand || (lane == kNumCand && has_ups);
-  Cand k{};
-  double v = -INFINITY;
-  bool evaluated = false;  // an empty overlap (flag 1) is not evaluated at all
-  if (mine) {
-    k = cand[(int64_t)p * kCandSlots + lane];
-    evaluated = k.flag != 1;
-    if (k.flag == 0) {
-      const unsigned long long* m = acc + ((int64_t)p * kCandSlots + lane) * 5;
-      const int ay = k.y < 0 ? -k.y : k.y, ax = k.x < 0 ? -k.x : k.x;
-      const unsigned long long n = (unsigned long long)(d.img_h - ay) * (unsigned long long)(d.img_w - ax);
-      v = ncc_from_moments(n, m[0], m[1], m[2], m[3], m[4]);
+  const Cand* my_cand = cand + (int64_t)p * slots;
+  const unsigned long long* my_acc = acc + (int64_t)p * slots * 5;
+  auto score = [&](const Cand& k, int index) -> double {
+    // a duplicate takes the value of the candidate it repeats (always an earlier, scored one: same moments)
+    const int src = k.flag == 3 ? k.dup_of : index;
+    const unsigned long long* m = my_acc + (int64_t)src * 5;
+    const int ay = k.y < 0 ? -k.y : k.y, ax = k.x < 0 ? -k.x : k.x;
+    const unsigned long long n = (unsigned long long)(d.img_h - ay) * (unsigned long long)(d.img_w - ax);
+    return ncc_from_moments(n, m[0], m[1], m[2], m[3], m[4]);
+  };
+  double best = -INFINITY;
+  int by = 0, bx = 0;
+  bool any = false;
+  for (int c0 = 0; c0 < n_cand; c0 += 64) {
+    const int ci = c0 + lane;
+    Cand k{0, 0, 1, -1};
+    double v = -INFINITY;
+    bool evaluated = false;  // an empty overlap (flag 1) is not evaluated at all
+    if (ci < n_cand) {
+      k = my_cand[ci];
+      evaluated = k.flag != 1;
+      if (k.flag == 0 || k.flag == 3) v = score(k, ci);
+      if (table != nullptr) {
+        double* row = table + ((int64_t)p * n_cand + ci) * 3;
+        row[0] = (double)k.y;
+        row[1] = (double)k.x;
+        row[2] = evaluated ? v : nan;
+      }
+    }
+    double chunk_best = evaluated ? v : -INFINITY;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) chunk_best = fmax(chunk_best, __shfl_xor(chunk_best, off));
+    const unsigned long long at_best = __ballot(evaluated && v == chunk_best && chunk_best != -INFINITY);
+    if (at_best && chunk_best > best) {  // strictly: an equal value later in the walk does not replace
+      const int win = __builtin_ctzll(at_best);
+      best = chunk_best;
+      by = __shfl(k.y, win);
+      bx = __shfl(k.x, win);
+      any = true;
     }
   }
-  // a duplicate takes the value of the candidate it repeats (always an earlier, scored one)
-  const double of_dup = __shfl(v, (mine && k.flag == 3) ? k.dup_of : lane);
-  if (mine && k.flag == 3) v = of_dup;
-  const bool discrete = lane < kNumCand && evaluated;
-  double best = discrete ? v : -INFINITY;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) best = fmax(best, __shfl_xor(best, off));
-  const unsigned long long at_best = __ballot(discrete && v == best && best != -INFINITY);
-  const int win = at_best ? __builtin_ctzll(at_best) : -1;
-  const int by = __shfl(k.y, win < 0 ? 0 : win), bx = __shfl(k.x, win < 0 ? 0 : win);
-  double oy = win < 0 ? 0.0 : (double)by, ox = win < 0 ? 0.0 : (double)bx;
-  // The subpixel estimate is scored at its rounded position and is listed BEFORE the
-  // discrete result (_translation_computation.py:1232-1313): it wins unless strictly worse.
-  const double v_ups = __shfl(v, kNumCand);
-  const int flag_ups = __shfl((int)k.flag, kNumCand);
-  if (has_ups && flag_ups == 0 && v_ups != -INFINITY && v_ups >= best) {
-    best = v_ups;
-    oy = d.transposed ? ups[p].sub_l : ups[p].sub_s;
-    ox = d.transposed ? ups[p].sub_s : ups[p].sub_l;
+  double oy = any ? (double)by : 0.0, ox = any ? (double)bx : 0.0;
+  const bool has_ups = ups != nullptr && ups[p].valid;
+  if (has_ups) {
+    const Cand ku = my_cand[n_cand];
+    if (ku.flag == 0) {
+      const double v_ups = score(ku, n_cand);
+      if (v_ups != -INFINITY && (wide ? v_ups > best : v_ups >= best)) {
+        best = v_ups;
+        oy = d.transposed ? ups[p].sub_l : ups[p].sub_s;
+        ox = d.transposed ? ups[p].sub_s : ups[p].sub_l;
+      }
+    }
   }
   if (lane == 0) {
     out[3 * p] = best;
@@ -2806,6 +2854,7 @@ struct RegWorkspace {
   Cand* cand;
   unsigned long long* acc;
   int partial_stride;
+  int n_cand = kNumCand;  // candidates per pair: 16 per peak the search consumes
   // subpixel stage (n_up = 0: off)
   int n_up = 0;
   double uf = 0.0;
@@ -2862,7 +2911,7 @@ static bool stage_all_pairs(const mistitch_ctx* ctx, int n_pairs, int chunk, int
 
 static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, int stage_slots, size_t staging_elems_per_pair,
                                 size_t spectrum_bytes_per_pair, size_t slab_bytes_per_pair, int partial_stride,
-                                RegWorkspace* ws) {
+                                RegWorkspace* ws, int n_cand = kNumCand) {
   int rc;
   if ((rc = ctx->desc.reserve((size_t)n_pairs * sizeof(PairDesc)))) return rc;
   if ((rc = ctx->staging.reserve((size_t)stage_slots * staging_elems_per_pair * 2 + 256))) return rc;
@@ -2870,8 +2919,9 @@ static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, int s
   if ((rc = ctx->slabs.reserve((size_t)chunk * slab_bytes_per_pair))) return rc;
   if ((rc = ctx->partial.reserve((size_t)chunk * partial_stride * sizeof(Peak)))) return rc;
   if ((rc = ctx->peaks.reserve((size_t)n_pairs * kMaxK * sizeof(Peak)))) return rc;
-  if ((rc = ctx->cand.reserve((size_t)n_pairs * kCandSlots * sizeof(Cand)))) return rc;
-  if ((rc = ctx->acc.reserve((size_t)n_pairs * kCandSlots * 5 * sizeof(unsigned long long)))) return rc;
+  if ((rc = ctx->cand.reserve((size_t)n_pairs * (n_cand + 1) * sizeof(Cand)))) return rc;
+  if ((rc = ctx->acc.reserve((size_t)n_pairs * (n_cand + 1) * 5 * sizeof(unsigned long long)))) return rc;
+  ws->n_cand = n_cand;
   ws->desc = (PairDesc*)ctx->desc.ptr;
   ws->staging = (uint16_t*)ctx->staging.ptr;
   ws->spectrum = ctx->spectrum.ptr;
@@ -2901,7 +2951,7 @@ static int launch_subpixel(mistitch_ctx* ctx, const UpsTables& tb, const RegWork
                            int n, int want_transposed, int S, int L, int Sr, int64_t pair_stride, const cx<T>* rslabs,
                            int nblk, int k) {
   int rc;
-  MS_REQUIRE(k >= 1 && k <= 2, MISTITCH_ERR_UNSUPPORTED, "the subpixel stage needs the two-peak search");
+  MS_REQUIRE(k >= 1 && k <= kMaxK, MISTITCH_ERR_UNSUPPORTED, "the subpixel stage needs a peak search");
   MS_LAUNCH(ctx, "k_ups_coarse", k_ups_coarse, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, S, L, want_transposed,
             ws.partial_abs, ws.abs_stride, nblk, ws.ups);
   // slabs per workgroup: two, so that two workgroups per CU overlap each other's staging (four measured
@@ -3047,7 +3097,7 @@ extern "C" int mistitch_debug_stamps(unsigned long long* host_out /*[3][4096][8]
 static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
                                int64_t tile_pitch, const void* ff, int ff_type, const int32_t* pair_idx,
                                const uint8_t* pair_dir, int n_pairs, int edge_width, unsigned flags, double* out,
-                               int8_t* status);
+                               int8_t* status, double* table = nullptr);
 
 extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int edge_width,
                                              int max_pairs, unsigned flags) {
@@ -3069,7 +3119,9 @@ extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int 
   // slots large enough for either direction, as a call with a flatfield stages both
   const int64_t slot_elems = 2 * std::max((int64_t)w_left * tile_h, (int64_t)w_top * tile_w);
   const int stage_slots = stage_all_pairs(ctx, max_pairs, chunk, slot_elems) ? max_pairs : chunk;
-  if ((rc = reserve_registration(ctx, max_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws))) return rc;
+  if ((rc = reserve_registration(ctx, max_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws,
+                                 (flags & MISTITCH_REG_PEAKS10) ? kNumCandWide : kNumCand)))
+    return rc;
   // Whatever else a first call sets up (tables of the subpixel stage, kernels that need their LDS limit
   // raised) is set up by making that call: max_pairs pairs of two blank tiles, left and top alternating.
   // Blank tiles are featureless, so the kernels leave early, but every launch of a real call is made.
@@ -3109,7 +3161,7 @@ extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int 
 static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
                                int64_t tile_pitch, const void* ff, int ff_type, const int32_t* pair_idx,
                                const uint8_t* pair_dir, int n_pairs, int edge_width, unsigned flags, double* out,
-                               int8_t* status) {
+                               int8_t* status, double* table) {
   MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
   MS_REQUIRE(n_pairs >= 0 && n_tiles >= 0, MISTITCH_ERR_ARG, "negative count");
   if (n_pairs == 0) return MISTITCH_OK;
@@ -3136,7 +3188,13 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
       2 * (ff != nullptr ? std::max((int64_t)w_left * H, (int64_t)w_top * W) : (int64_t)w_left * H);
   const bool stage_all = stage_all_pairs(ctx, n_pairs, chunk, slot_elems);
   const int stage_slots = stage_all ? n_pairs : chunk;
-  if ((rc = reserve_registration(ctx, n_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws))) return rc;
+  // peaks the candidate search consumes: 2 (the reference's discrete search), or 10 (the candidate set of its
+  // consensus stage, generate_translation_candidates at _translation_computation.py:876-994)
+  const bool wide = (flags & MISTITCH_REG_PEAKS10) != 0;
+  const int k = wide ? 10 : 2;
+  static_assert(kNumCand == 16 * 2 && kNumCandWide == 16 * 10, "16 signed interpretations per peak");
+  if ((rc = reserve_registration(ctx, n_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws, 16 * k)))
+    return rc;
   const bool subpixel = (flags & MISTITCH_REG_SUBPIXEL) != 0;
   if (subpixel) {
     if ((rc = reserve_subpixel(ctx, n_pairs, chunk, std::max(cfg_left.nblk, cfg_top.nblk),
@@ -3149,8 +3207,6 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
   const bool vec_strips = ff != nullptr ? aligned16(ws.staging) && (W % 8 == 0) && (slot_elems % 8 == 0) &&
                                               (((int64_t)w_top * W) % 8 == 0)
                                         : vec_top;
-  const int k = 2;  // peaks the candidate search consumes
-
   MS_LAUNCH(ctx, "k_setup_pairs", k_setup_pairs, dim3((n_pairs + 255) / 256), dim3(256), 0, tiles, tile_pitch, H, W, w_left,
                      w_top, pair_idx, pair_dir, n_pairs, n_tiles, ws.staging, stage_slots, ws.desc, status, slot_elems,
                      ff != nullptr ? 1 : 0);
@@ -3196,8 +3252,9 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
     return MISTITCH_OK;
   };
   auto candidates = [&](int pair0, int n) {
-    MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(kXcds * ((n + kXcds - 1) / kXcds) * kCandSlots * kNccChunks),
-              dim3(kThreads), 0, ws.desc, status, pair0, n, ws.cand, ws.acc);
+    MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate,
+              dim3(kXcds * ((n + kXcds - 1) / kXcds) * (ws.n_cand + 1) * kNccChunks), dim3(kThreads), 0, ws.desc, status, pair0,
+              n, ws.cand, ws.acc, ws.n_cand);
   };
   if (stage_all && (rc = stage(0, n_pairs))) return rc;
   for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {
@@ -3211,15 +3268,15 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
       if ((rc = launch_any(ctx, cfg_top, f64, ws, status, pair0, n, 0, vec_strips, k, nullptr))) return rc;
     }
     MS_LAUNCH(ctx, "k_peaks_candidates", k_peaks_candidates, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, ws.partial,
-                       ws.partial_stride, cfg_top.nblk, cfg_left.nblk, k, 2, ws.peaks, ws.cand, ws.acc);
+                       ws.partial_stride, cfg_top.nblk, cfg_left.nblk, k, k, ws.peaks, ws.cand, ws.acc);
     if (subpixel)
       MS_LAUNCH(ctx, "k_ups_finish", k_ups_finish, dim3((n + 63) / 64), dim3(64), 0, ws.desc, status, pair0, n, ws.partial_ups,
-                ws.n_row_blocks, ws.n_up, ws.uf, ws.ups, ws.cand);
+                ws.n_row_blocks, ws.n_up, ws.uf, ws.ups, ws.cand, ws.n_cand);
     if (!stage_all) candidates(pair0, n);
   }
   if (stage_all) candidates(0, n_pairs);
   MS_LAUNCH(ctx, "k_finalize", k_finalize, dim3((n_pairs + 3) / 4), dim3(256), 0, ws.desc, status, n_pairs, ws.cand, ws.acc,
-                     out, status, subpixel ? ws.ups : (const UpsState*)nullptr);
+                     out, status, subpixel ? ws.ups : (const UpsState*)nullptr, ws.n_cand, wide ? 1 : 0, table);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }
@@ -3241,6 +3298,20 @@ extern "C" int mistitch_register_pairs_flatfield(mistitch_ctx* ctx, const uint16
              ff_type);
   return register_pairs_impl(ctx, tiles, n_tiles, tile_h, tile_w, tile_pitch, flatfield, ff_type, pair_idx, pair_dir,
                              n_pairs, edge_width, flags, out, status);
+}
+
+extern "C" int mistitch_register_pairs_candidates(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h,
+                                                  int tile_w, int64_t tile_pitch, const void* flatfield, int ff_type,
+                                                  const int32_t* pair_idx, const uint8_t* pair_dir, int n_pairs,
+                                                  int edge_width, unsigned flags, double* out, int8_t* status,
+                                                  double* table) {
+  MS_REQUIRE(table, MISTITCH_ERR_ARG, "table is NULL");
+  MS_REQUIRE(ff_type == MISTITCH_FF_NONE || ff_type == MISTITCH_FF_F32 || ff_type == MISTITCH_FF_F64, MISTITCH_ERR_ARG,
+             "unknown flatfield type %d", ff_type);
+  MS_REQUIRE((ff_type == MISTITCH_FF_NONE) == (flatfield == nullptr), MISTITCH_ERR_ARG,
+             "flatfield and its type disagree");
+  return register_pairs_impl(ctx, tiles, n_tiles, tile_h, tile_w, tile_pitch, flatfield, ff_type, pair_idx, pair_dir,
+                             n_pairs, edge_width, flags, out, status, table);
 }
 
 // Shared body of mistitch_pcm / mistitch_pcm_topk: one pair of free-standing strips.
@@ -3315,7 +3386,7 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   if ((rc = launch_any(ctx, cfg, f64, ws, status, 0, 1, -1, vec, k, out_pcm))) return rc;
   if (sub_out != nullptr) {
     MS_LAUNCH(ctx, "k_ups_finish", k_ups_finish, dim3(1), dim3(64), 0, ws.desc, status, 0, 1, ws.partial_ups, ws.n_row_blocks,
-              ws.n_up, ws.uf, ws.ups, ws.cand);
+              ws.n_up, ws.uf, ws.ups, ws.cand, ws.n_cand);
     MS_LAUNCH(ctx, "k_ups_to_array", k_ups_to_array, dim3(1), dim3(64), 0, ws.desc, ws.ups, sub_out);
     MS_HIP(hipGetLastError());
     return MISTITCH_OK;

@@ -16,7 +16,8 @@ from typing import Dict, List, Optional, Sequence, Set, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import FFT_F32, FFT_F64, PAIR_FEATURELESS, PAIR_NO_CANDIDATE, PAIR_OK, REG_SUBPIXEL, check, lib, ptr
+from ._lib import (FFT_F32, FFT_F64, PAIR_FEATURELESS, PAIR_NO_CANDIDATE, PAIR_OK, REG_PEAKS10, REG_SUBPIXEL, check, lib,
+                   ptr)
 
 logger = logging.getLogger(__name__)
 
@@ -74,7 +75,7 @@ def to_device_u16(arr, device=None):
 # ----------------------------------------------------------------------------
 def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WIDTH, fft: str = "f64",
                    ctx: Optional[_lib.Context] = None, out=None, status=None, subpixel: bool = False,
-                   upsample_factor: int = 100, flatfield=None):
+                   upsample_factor: int = 100, flatfield=None, peaks10: bool = False, return_candidates: bool = False):
     """Register every (first, second) tile pair on the device.
 
     tiles     [N, H, W] uint16 CUDA tensor (or NumPy array, uploaded)
@@ -89,6 +90,11 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
     ``flatfield`` ([H, W] float32 or float64): the tiles are raw and the strips are corrected
     on the way, with the results of correcting whole tiles first
     (apply_flatfield_to_image, tile_registration.py:2142-2181).
+    ``peaks10``: walk the 16 interpretations of the ten best peaks, the candidate set of the
+    reference's consensus stage (generate_translation_candidates(n=10),
+    _translation_computation.py:876-994) with its best-NCC fallback (:1112-1118) as the result.
+    ``return_candidates``: also return the table [P, 32 or 160, 3] (y, x, ncc; strip relative) of
+    every candidate in evaluation order, NaN ncc where the reference does not score it.
     """
     torch = _torch()
     tiles = to_device_u16(tiles)
@@ -112,6 +118,9 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
     if subpixel:
         ctx.set_upsample_factor(upsample_factor)
         flags |= REG_SUBPIXEL
+    if peaks10:
+        flags |= REG_PEAKS10
+    ff, ff_type = None, _lib.FF_NONE
     if flatfield is not None:
         ff = flatfield if isinstance(flatfield, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(flatfield))
         if tuple(ff.shape) != (h, w):
@@ -120,6 +129,13 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
             ff = ff.to(torch.float64)
         ff = ff.to(dev).contiguous()
         ff_type = _lib.FF_F32 if ff.dtype == torch.float32 else _lib.FF_F64
+    if return_candidates:
+        table = torch.empty((n_pairs, 160 if peaks10 else 32, 3), dtype=torch.float64, device=dev)
+        check(lib.mistitch_register_pairs_candidates(ctx.handle, ptr(tiles), n, h, w, h * w, ptr(ff), ff_type, ptr(pi),
+                                                     ptr(pd_), n_pairs, int(edge_width), flags, ptr(out), ptr(status),
+                                                     ptr(table)))
+        return out, status, table
+    if ff is not None:
         check(lib.mistitch_register_pairs_flatfield(ctx.handle, ptr(tiles), n, h, w, h * w, ptr(ff), ff_type, ptr(pi),
                                                     ptr(pd_), n_pairs, int(edge_width), flags, ptr(out), ptr(status)))
         return out, status

@@ -41,6 +41,7 @@ extern "C" {
 #define MISTITCH_FFT_F64 0u /* complex128 spectra, as the reference computes them (default) */
 #define MISTITCH_FFT_F32 1u /* complex64 spectra: half the traffic, PCM differs at ~1e-7     */
 #define MISTITCH_REG_SUBPIXEL 2u /* mistitch_register_pairs: add the upsampled-DFT estimate    */
+#define MISTITCH_REG_PEAKS10 4u  /* mistitch_register_pairs: search the 10 best peaks (160 candidates) */
 
 /* fusion modes */
 #define MISTITCH_FUSE_OVERWRITE 0 /* last writer wins, the reference behaviour */
@@ -130,6 +131,29 @@ int mistitch_register_pairs_flatfield(mistitch_ctx* ctx, const uint16_t* tiles, 
                                       int tile_w, int64_t tile_pitch, const void* flatfield, int ff_type,
                                       const int32_t* pair_idx, const uint8_t* pair_dir, int n_pairs,
                                       int edge_width, unsigned flags, double* out, int8_t* status);
+
+/* Flag MISTITCH_REG_PEAKS10: the candidate search walks the 16 signed interpretations of the TEN
+ * largest PCM peaks instead of two: the candidate set of the reference's "Method 1"
+ * (generate_translation_candidates(n=10), _translation_computation.py:876-994), whose
+ * best-NCC candidate is what that method returns whenever its consensus step declines
+ * (ransac_translation_estimation, :1019-1038 and :1112-1118).  The consensus step itself
+ * (scikit-image's ransac on an unseeded random state, :1077-1084) is not reproduced.  The
+ * result is the first candidate of the walk that no other beats; with MISTITCH_REG_SUBPIXEL
+ * as well the subpixel estimate only wins when strictly better (Method 1 is listed first).
+ *
+ * mistitch_register_pairs_candidates: mistitch_register_pairs (flatfield == NULL, ff_type
+ * MISTITCH_FF_NONE) or mistitch_register_pairs_flatfield, plus the table the walk scored:
+ *   table      [n_pairs][n_cand][3] float64, n_cand = 32 (160 with MISTITCH_REG_PEAKS10):
+ *              y, x (strip relative, before the strip offset is added) and ncc of every
+ *              candidate in the reference's evaluation order; ncc is NaN where the
+ *              reference does not score the candidate (empty overlap, fewer peaks than
+ *              asked for) and -inf for an overlap of fewer than 25 pixels; rows of
+ *              featureless pairs are NaN                                                  */
+int mistitch_register_pairs_candidates(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h,
+                                       int tile_w, int64_t tile_pitch, const void* flatfield, int ff_type,
+                                       const int32_t* pair_idx, const uint8_t* pair_dir, int n_pairs,
+                                       int edge_width, unsigned flags, double* out, int8_t* status,
+                                       double* table);
 
 /* Integer hill climb of the strip NCC around given start shifts: from start_yx the
  * best of the 3 x 3 integer neighbours (first of equal maxima, row-major) is taken

@@ -196,6 +196,86 @@ def interpret_translation(strip1: np.ndarray, strip2: np.ndarray,
 
 
 # ----------------------------------------------------------------------------
+# a-7  "Method 1", deterministic part                      tc:876-994, 1019-1038, 1112-1118
+# ----------------------------------------------------------------------------
+def generate_translation_candidates(strip1: np.ndarray, strip2: np.ndarray, yins: Sequence[int], xins: Sequence[int],
+                                    ymin: int, ymax: int, xmin: int, xmax: int, n: int = 10):
+    """(translations [N, 2] float, ncc_scores [N]) of the candidates of the first ``n`` valid peaks whose
+    NCC is finite, in evaluation order (tc:876-994): what the reference hands to its consensus step."""
+    size_y, size_x = strip1.shape
+    yins, xins = np.asarray(yins), np.asarray(xins)
+    if yins.size == 0:
+        return np.empty((0, 2)), np.empty((0,))
+    ymin, ymax, xmin, xmax = int(ymin), int(ymax), int(xmin), int(xmax)
+    picked = [i for i in range(yins.size)
+              if _peak_is_valid(int(yins[i]), int(xins[i]), size_y, size_x, ymin, ymax, xmin, xmax)][: int(n)] \
+        if not (ymin <= -size_y and ymax >= size_y and xmin <= -size_x and xmax >= size_x) \
+        else list(range(min(int(n), yins.size)))
+    translations, scores = [], []
+    for i in picked:
+        for (y, x) in candidate_table(int(yins[i]), int(xins[i]), size_y, size_x):
+            if not (ymin <= y <= ymax and xmin <= x <= xmax):
+                continue
+            sub1 = extract_overlap_subregion(strip1, y, x)
+            sub2 = extract_overlap_subregion(strip2, -y, -x)
+            if sub1.size == 0 or sub2.size == 0:
+                continue
+            v = ncc(sub1, sub2)
+            if np.isnan(v) or v == float("-inf"):
+                continue
+            translations.append([float(y), float(x)])
+            scores.append(v)
+    if not translations:
+        return np.empty((0, 2)), np.empty((0,))
+    return np.array(translations), np.array(scores)
+
+
+def best_single_translation(translations: np.ndarray, scores: np.ndarray):
+    """What ransac_translation_estimation returns whenever the consensus is unavailable or declined
+    (tc:1019-1038, 1112-1118, 1129-1140): the FIRST candidate of the largest NCC."""
+    if len(translations) == 0:
+        return None
+    i = int(np.argmax(scores))
+    return float(scores[i]), float(translations[i][0]), float(translations[i][1])
+
+
+def compute_translation_peaks10(strip1, strip2, yins, xins, ymin, ymax, xmin, xmax, n: int = 10):
+    """The reference's result list with Method 1 standing on its best-NCC fallback: (method 1, discrete search),
+    first of equal scores (tc:1195-1230, 1274-1313)."""
+    results = []
+    t, sc = generate_translation_candidates(strip1, strip2, yins, xins, ymin, ymax, xmin, xmax, n)
+    m1 = best_single_translation(t, sc)
+    if m1 is not None and ymin <= m1[1] <= ymax and xmin <= m1[2] <= xmax and np.isfinite(m1[0]):
+        results.append(m1)
+    d = interpret_translation(strip1, strip2, yins, xins, ymin, ymax, xmin, xmax, min(int(n), 2))
+    if d[0] != float("-inf"):
+        results.append((d[0], float(d[1]), float(d[2])))
+    if not results:
+        return float("-inf"), 0.0, 0.0
+    return max(results, key=lambda r: r[0])
+
+
+def register_pairs_peaks10(tiles: np.ndarray, pair_idx, directions: Sequence[int], edge_width: int):
+    """``register_pairs`` with the 160-candidate walk; also returns every pair's (translations, scores)."""
+    pair_idx = np.asarray(pair_idx).reshape(-1, 2)
+    out = np.full((len(pair_idx), 3), np.nan, dtype=np.float64)
+    status = np.zeros(len(pair_idx), dtype=np.int8)
+    tables = []
+    for p, (i1, i2) in enumerate(pair_idx):
+        e1, e2, off_y, off_x = edge_strips(tiles[i1], tiles[i2], "top" if directions[p] else "left", edge_width)
+        if e1.size == 0 or e2.size == 0 or is_edge_featureless(e1) or is_edge_featureless(e2):
+            status[p] = 1
+            tables.append(None)
+            continue
+        eh, ew = e1.shape
+        yins, xins, _ = multi_peak_max(pcm(e1, e2))
+        tables.append(generate_translation_candidates(e1, e2, yins, xins, -eh, eh, -ew, ew, 10))
+        score, y, x = compute_translation_peaks10(e1, e2, yins, xins, -eh, eh, -ew, ew, 10)
+        out[p] = (score, y + off_y, x + off_x)
+    return out, status, tables
+
+
+# ----------------------------------------------------------------------------
 # a-8  bounded least-squares polish                               tc:1466-1588
 # ----------------------------------------------------------------------------
 def optimize_translation_continuous(strip1, strip2, y0: float, x0: float,

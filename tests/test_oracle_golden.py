@@ -121,3 +121,53 @@ def test_polish_never_changes_the_discrete_result(golden):
     a, _ = oreg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, spec["edge_width"], polish=True)
     b, _ = oreg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, spec["edge_width"], polish=False)
     assert np.array_equal(a, b)
+
+
+def _m1_golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "m1_golden.json")) as fh:
+        return json.load(fh)
+
+
+def m1_strips(s):
+    """The strip pair of one m1_golden.json case, as tests/golden/make_golden_m1.py builds it."""
+    h, w = s["shape"]
+    dy, dx = s["shift"]
+    big = synth.make_scene(s["seed"], h + 64, w + 64)
+    if s["smooth"]:
+        f = np.fft.fft2(big.astype(np.float64))
+        k = np.fft.fftfreq(h + 64)[:, None] ** 2 + np.fft.fftfreq(w + 64)[None, :] ** 2
+        low = np.fft.ifft2(f * np.exp(-k * 2000.0)).real
+        big = (1000 + 50000 * (low - low.min()) / (low.max() - low.min())).astype(np.uint16)
+    return (np.ascontiguousarray(big[32:32 + h, 32:32 + w]),
+            np.ascontiguousarray(big[32 + dy:32 + dy + h, 32 + dx:32 + dx + w]))
+
+
+def test_method1_candidates_match_the_reference():
+    """The deterministic part of the reference's Method 1 (its candidate set and the best-NCC fallback of its
+    consensus step), restated in the oracle, against vectors made by running the reference."""
+    doc = _m1_golden()
+    for s in doc["strips"]:
+        a, b = m1_strips(s)
+        h, w = s["shape"]
+        yi, xi, _ = oreg.multi_peak_max(oreg.pcm(a, b))
+        assert [[int(yi[i]), int(xi[i])] for i in range(10)] == s["peaks"], s["name"]
+        t, sc = oreg.generate_translation_candidates(a, b, yi, xi, -h, h, -w, w, 10)
+        assert np.array_equal(t, np.array(s["translations"])), s["name"]
+        assert np.allclose(sc, np.array(s["scores"]), rtol=0, atol=1e-12), s["name"]
+        best = oreg.best_single_translation(t, sc)
+        assert best[1:] == tuple(s["fallback"][1:]) and abs(best[0] - s["fallback"][0]) < 1e-12
+        got = oreg.compute_translation_peaks10(a, b, yi, xi, -h, h, -w, w, 10)
+        assert got[1:] == tuple(s["fallback"][1:])            # never worse than the two-peak search
+        assert s["fallback"][0] >= s["discrete"][0]
+    for g in doc["grids"]:
+        grid = synth.make_grid(g["seed"], g["rows"], g["cols"], g["tile_h"], g["tile_w"], overlap=g["overlap"], jitter=g["jitter"])
+        out, status, tables = oreg.register_pairs_peaks10(grid.tiles, grid.pair_idx, grid.pair_dir, g["edge_width"])
+        for p, exp in enumerate(g["pairs"]):
+            assert (exp is None) == (status[p] != 0)
+            if exp is None:
+                continue
+            assert len(tables[p][1]) == exp["n"]
+            assert tuple(out[p, 1:]) == tuple(exp["fallback"][1:]) and abs(out[p, 0] - exp["fallback"][0]) < 1e-12
+            assert abs(float(np.sum(tables[p][1])) - exp["score_sum"]) < 1e-9
