@@ -23,6 +23,7 @@ PAIR_OK, PAIR_FEATURELESS, PAIR_NO_CANDIDATE = 0, 1, 2
 FFT_F64, FFT_F32 = 0, 1
 REG_SUBPIXEL = 2
 REG_PEAKS10 = 4
+REG_WINDOW_HANN = 8
 FUSE_OVERWRITE, FUSE_FEATHER = 0, 1
 FF_NONE, FF_F32, FF_F64 = 0, 1, 2
 

@@ -160,5 +160,6 @@ struct mistitch_ctx {
   std::vector<void*> shape_allocs;                // device tables owned by those configurations
   std::map<int, std::vector<char>> gen_plans;     // chirp-z plans by transform length
   std::map<long long, void*> gen_tables;          // subpixel column tables of chirp-z strip shapes (freed with shape_allocs)
+  std::map<int, void*> hann_tables;               // symmetric Hann windows by length, float64 (freed with shape_allocs)
   mistitch::Profiler prof;
 };

@@ -573,10 +573,14 @@ __global__ void k_transpose_plain(const uint16_t* src, int64_t pitch, int h, int
 
 // ---------------------------------------------------------------------------
 // Forward FFT along the long axis.  grid (S / NF, pairs_in_pass).
-template <typename T, bool VEC>
+// WIN: every pixel is multiplied by a separable window, win_s[line] * win_l[column] (float64 tables), on its
+// way into the transform (MISTITCH_REG_WINDOW_HANN; the reference applies none).
+template <typename T, bool VEC, bool WIN = false>
 __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc, const int8_t* status,
                                                            int pair0, int S, int L, int want_transposed,
-                                                           FftPlanDev planL, int NF, cx<T>* slabs) {
+                                                           FftPlanDev planL, int NF, cx<T>* slabs,
+                                                           const double* __restrict__ win_s = nullptr,
+                                                           const double* __restrict__ win_l = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
   const int p = pair0 + blockIdx.y;
@@ -613,10 +617,20 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
         if (e < NF * L) {
           const int f = e >> lL, i = e & (L - 1);
           const unsigned wa[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, wb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+          if constexpr (WIN) {
+            const double ws = win_s[s0 + f];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            buf[addr(f, i + 2 * q)] = mk<T>((T)(wa[q] & 0xffffu), (T)(wb[q] & 0xffffu));
-            buf[addr(f, i + 2 * q + 1)] = mk<T>((T)(wa[q] >> 16), (T)(wb[q] >> 16));
+            for (int q = 0; q < 4; ++q) {
+              const double w0 = ws * win_l[i + 2 * q], w1 = ws * win_l[i + 2 * q + 1];
+              buf[addr(f, i + 2 * q)] = mk<T>((T)((double)(wa[q] & 0xffffu) * w0), (T)((double)(wb[q] & 0xffffu) * w0));
+              buf[addr(f, i + 2 * q + 1)] = mk<T>((T)((double)(wa[q] >> 16) * w1), (T)((double)(wb[q] >> 16) * w1));
+            }
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              buf[addr(f, i + 2 * q)] = mk<T>((T)(wa[q] & 0xffffu), (T)(wb[q] & 0xffffu));
+              buf[addr(f, i + 2 * q + 1)] = mk<T>((T)(wa[q] >> 16), (T)(wb[q] >> 16));
+            }
           }
         }
       }
@@ -624,7 +638,13 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
   } else {
     for (int e = tid; e < NF * L; e += kThreads) {
       const int f = e >> lL, i = e & (L - 1);
-      buf[addr(f, i)] = mk<T>((T)d.a[(int64_t)(s0 + f) * d.pitch + i], (T)d.b[(int64_t)(s0 + f) * d.pitch + i]);
+      const T va = (T)d.a[(int64_t)(s0 + f) * d.pitch + i], vb = (T)d.b[(int64_t)(s0 + f) * d.pitch + i];
+      if constexpr (WIN) {
+        const double w = win_s[s0 + f] * win_l[i];
+        buf[addr(f, i)] = mk<T>((T)((double)va * w), (T)((double)vb * w));
+      } else {
+        buf[addr(f, i)] = mk<T>(va, vb);
+      }
     }
   }
   __syncthreads();
@@ -1155,7 +1175,9 @@ __global__ __launch_bounds__(kGenShortThreads) void k_fft_short_cps_gen(const Pa
 
 // z = a + i b per line, length-L transform, natural order out.  grid (S, pairs_in_pass).
 __global__ __launch_bounds__(kThreads) void k_gen_rows_fwd(const PairDesc* desc, const int8_t* status, int pair0, int S,
-                                                           int L, int want_transposed, GenPlanDev gp, double2* Zf) {
+                                                           int L, int want_transposed, GenPlanDev gp, double2* Zf,
+                                                           const double* __restrict__ win_s,
+                                                           const double* __restrict__ win_l) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double2* buf = reinterpret_cast<double2*>(smem_raw);
   const int p = pair0 + blockIdx.y;
@@ -1166,8 +1188,11 @@ __global__ __launch_bounds__(kThreads) void k_gen_rows_fwd(const PairDesc* desc,
   const LineAddr<double> addr{LineAddr<double>::padded(gp.M) + 1};
   const Twiddles<double> tw = load_twiddles<double>(buf + addr.fstride, gp.planM, tid, kThreads);
   const int s = blockIdx.x;
-  for (int i = tid; i < L; i += kThreads)
-    buf[addr(0, i)] = mk<double>((double)d.a[(int64_t)s * d.pitch + i], (double)d.b[(int64_t)s * d.pitch + i]);
+  const double ws = win_s != nullptr ? win_s[s] : 1.0;  // optional separable window (none in the reference)
+  for (int i = tid; i < L; i += kThreads) {
+    const double w = win_l != nullptr ? ws * win_l[i] : 1.0;
+    buf[addr(0, i)] = mk<double>((double)d.a[(int64_t)s * d.pitch + i] * w, (double)d.b[(int64_t)s * d.pitch + i] * w);
+  }
   __syncthreads();
   bluestein_lines(buf, addr, 1, gp, tw, false, tid, kThreads);
   double2* out = Zf + ((int64_t)blockIdx.y * S + s) * L;
@@ -2855,6 +2880,7 @@ struct RegWorkspace {
   unsigned long long* acc;
   int partial_stride;
   int n_cand = kNumCand;  // candidates per pair: 16 per peak the search consumes
+  bool window = false;    // MISTITCH_REG_WINDOW_HANN
   // subpixel stage (n_up = 0: off)
   int n_up = 0;
   double uf = 0.0;
@@ -2980,6 +3006,24 @@ static int launch_subpixel(mistitch_ctx* ctx, const UpsTables& tb, const RegWork
   return MISTITCH_OK;
 }
 
+// Device table of the symmetric Hann window of length n, w[i] = 0.5 - 0.5 cos(2 pi i / (n - 1)) (numpy.hanning;
+// 1 for n = 1), built on first use.
+static int get_hann(mistitch_ctx* ctx, int n, const double** out) {
+  auto it = ctx->hann_tables.find(n);
+  if (it == ctx->hann_tables.end()) {
+    std::vector<double> w((size_t)n);
+    const double pi = 3.14159265358979323846;
+    for (int i = 0; i < n; ++i) w[i] = n == 1 ? 1.0 : 0.5 + 0.5 * cos(pi * (double)(1 - n + 2 * i) / (double)(n - 1));
+    void* dev = nullptr;
+    MS_HIP(hipMalloc(&dev, (size_t)n * sizeof(double)));
+    ctx->shape_allocs.push_back(dev);
+    MS_HIP(hipMemcpy(dev, w.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    it = ctx->hann_tables.emplace(n, dev).first;
+  }
+  *out = reinterpret_cast<const double*>(it->second);
+  return MISTITCH_OK;
+}
+
 // The three FFT kernels for pairs [pair0, pair0 + n) of one canonical shape.
 template <typename T>
 static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace& ws, const int8_t* status,
@@ -2987,14 +3031,29 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
   cx<T>* spec = reinterpret_cast<cx<T>*>(ws.spectrum);
   cx<T>* slabs = reinterpret_cast<cx<T>*>(ws.slabs);
   int rc;
-  if (vec_ok) {
+  if (ws.window) {
+    const double *win_s = nullptr, *win_l = nullptr;
+    if ((rc = get_hann(ctx, cfg.S, &win_s))) return rc;
+    if ((rc = get_hann(ctx, cfg.L, &win_l))) return rc;
+    if (vec_ok) {
+      if ((rc = allow_lds(ctx, k_fft_long_fwd<T, true, true>, cfg.lds_fwd))) return rc;
+      MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd<T, true, true>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads),
+                cfg.lds_fwd, ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, slabs, win_s, win_l);
+    } else {
+      if ((rc = allow_lds(ctx, k_fft_long_fwd<T, false, true>, cfg.lds_fwd))) return rc;
+      MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd<T, false, true>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads),
+                cfg.lds_fwd, ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, slabs, win_s, win_l);
+    }
+  } else if (vec_ok) {
     if ((rc = allow_lds(ctx, k_fft_long_fwd<T, true>, cfg.lds_fwd))) return rc;
     MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd<T, true>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd,
-                       ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, slabs);
+                       ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, slabs,
+                       (const double*)nullptr, (const double*)nullptr);
   } else {
     if ((rc = allow_lds(ctx, k_fft_long_fwd<T, false>, cfg.lds_fwd))) return rc;
     MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd<T, false>), dim3(cfg.S / cfg.NF_fwd, n), dim3(kThreads), cfg.lds_fwd,
-                       ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, slabs);
+                       ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.NF_fwd, slabs,
+                       (const double*)nullptr, (const double*)nullptr);
   }
   const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
   bool column_pass_done = false;
@@ -3042,8 +3101,13 @@ static int launch_fft_general(mistitch_ctx* ctx, const GenShape& g, const RegWor
   if ((rc = allow_lds(ctx, k_gen_rows_inv, g.lds_rows))) return rc;
   const double eps = std::numeric_limits<double>::epsilon() * 100.0;
   const int col_blocks = (g.L + g.C - 1) / g.C;
+  const double *win_s = nullptr, *win_l = nullptr;
+  if (ws.window) {
+    if ((rc = get_hann(ctx, g.S, &win_s))) return rc;
+    if ((rc = get_hann(ctx, g.L, &win_l))) return rc;
+  }
   MS_LAUNCH(ctx, "k_gen_rows_fwd", k_gen_rows_fwd, dim3(g.S, n), dim3(kThreads), g.lds_rows, ws.desc, status, pair0, g.S, g.L,
-            want_transposed, g.pl, Zf);
+            want_transposed, g.pl, Zf, win_s, win_l);
   MS_LAUNCH(ctx, "k_gen_cols", k_gen_cols, dim3(col_blocks, n), dim3(kThreads), g.lds_cols, ws.desc, status, pair0, g.S, g.L,
             want_transposed, g.ps, g.C, 0, Zf);
   const int cps_blocks = std::max(1, std::min(1024, (g.S * g.L + kThreads - 1) / kThreads));
@@ -3195,6 +3259,7 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
   static_assert(kNumCand == 16 * 2 && kNumCandWide == 16 * 10, "16 signed interpretations per peak");
   if ((rc = reserve_registration(ctx, n_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws, 16 * k)))
     return rc;
+  ws.window = (flags & MISTITCH_REG_WINDOW_HANN) != 0;
   const bool subpixel = (flags & MISTITCH_REG_SUBPIXEL) != 0;
   if (subpixel) {
     if ((rc = reserve_subpixel(ctx, n_pairs, chunk, std::max(cfg_left.nblk, cfg_top.nblk),
@@ -3342,6 +3407,7 @@ static int single_pair_pcm(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pi
   RegWorkspace ws;
   // the staging slot holds BOTH strips (transposed, or re-pitched) one after the other
   if ((rc = reserve_registration(ctx, 1, 1, 1, (size_t)2 * S * L, cfg.spec_bytes, cfg.slab_bytes, pstride, &ws))) return rc;
+  ws.window = (flags & MISTITCH_REG_WINDOW_HANN) != 0;
   if (sub_out != nullptr) {
     if ((rc = reserve_subpixel(ctx, 1, 1, cfg.nblk, cfg.n_stored, upsample, &ws))) return rc;
   }

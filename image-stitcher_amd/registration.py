@@ -16,8 +16,8 @@ from typing import Dict, List, Optional, Sequence, Set, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import (FFT_F32, FFT_F64, PAIR_FEATURELESS, PAIR_NO_CANDIDATE, PAIR_OK, REG_PEAKS10, REG_SUBPIXEL, check, lib,
-                   ptr)
+from ._lib import (FFT_F32, FFT_F64, PAIR_FEATURELESS, PAIR_NO_CANDIDATE, PAIR_OK, REG_PEAKS10, REG_SUBPIXEL,
+                   REG_WINDOW_HANN, check, lib, ptr)
 
 logger = logging.getLogger(__name__)
 
@@ -45,11 +45,15 @@ def _torch():
     return torch
 
 
-def _fft_flag(fft: str) -> int:
+def _fft_flag(fft: str, window: Optional[str] = None) -> int:
+    """Library flags for an FFT precision and an optional window ("hann"; the reference applies none)."""
+    if window not in (None, "hann"):
+        raise ValueError(f"unknown window {window!r}")
+    w = REG_WINDOW_HANN if window == "hann" else 0
     if fft in ("f64", "float64", "complex128"):
-        return FFT_F64
+        return FFT_F64 | w
     if fft in ("f32", "float32", "complex64"):
-        return FFT_F32
+        return FFT_F32 | w
     raise ValueError(f"unknown fft precision {fft!r}")
 
 
@@ -75,7 +79,8 @@ def to_device_u16(arr, device=None):
 # ----------------------------------------------------------------------------
 def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WIDTH, fft: str = "f64",
                    ctx: Optional[_lib.Context] = None, out=None, status=None, subpixel: bool = False,
-                   upsample_factor: int = 100, flatfield=None, peaks10: bool = False, return_candidates: bool = False):
+                   upsample_factor: int = 100, flatfield=None, peaks10: bool = False, return_candidates: bool = False,
+                   window: Optional[str] = None):
     """Register every (first, second) tile pair on the device.
 
     tiles     [N, H, W] uint16 CUDA tensor (or NumPy array, uploaded)
@@ -93,6 +98,8 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
     ``peaks10``: walk the 16 interpretations of the ten best peaks, the candidate set of the
     reference's consensus stage (generate_translation_candidates(n=10),
     _translation_computation.py:876-994) with its best-NCC fallback (:1112-1118) as the result.
+    ``window="hann"``: both strips are multiplied by a separable Hann window before the transforms (own
+    extension, off by default: the reference applies none); the candidate NCCs stay on raw pixels.
     ``return_candidates``: also return the table [P, 32 or 160, 3] (y, x, ncc; strip relative) of
     every candidate in evaluation order, NaN ncc where the reference does not score it.
     """
@@ -114,7 +121,7 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
         status = torch.empty((n_pairs,), dtype=torch.int8, device=dev)
     ctx = ctx or _lib.default_context()
     n, h, w = (int(s) for s in tiles.shape)
-    flags = _fft_flag(fft)
+    flags = _fft_flag(fft, window)
     if subpixel:
         ctx.set_upsample_factor(upsample_factor)
         flags |= REG_SUBPIXEL
@@ -253,7 +260,8 @@ def _validate_pair(image1, image2) -> None:
         raise ValueError(f"Images must have same shape. Got {image1.shape} and {image2.shape}")
 
 
-def pcm(image1: np.ndarray, image2: np.ndarray, fft: str = "f64", ctx: Optional[_lib.Context] = None) -> np.ndarray:
+def pcm(image1: np.ndarray, image2: np.ndarray, fft: str = "f64", ctx: Optional[_lib.Context] = None,
+        window: Optional[str] = None) -> np.ndarray:
     """Peak correlation matrix of two uint16 strips (_translation_computation.py:282-340)."""
     torch = _torch()
     _validate_pair(image1, image2)
@@ -262,14 +270,15 @@ def pcm(image1: np.ndarray, image2: np.ndarray, fft: str = "f64", ctx: Optional[
     out = torch.empty((h, w), dtype=torch.float64, device=a.device)
     ctx = ctx or _lib.default_context()
     try:
-        check(lib.mistitch_pcm(ctx.handle, ptr(a), w, ptr(b), w, h, w, _fft_flag(fft), ptr(out)))
+        check(lib.mistitch_pcm(ctx.handle, ptr(a), w, ptr(b), w, h, w, _fft_flag(fft, window), ptr(out)))
     except _lib.MistitchError as exc:
         raise RuntimeError(f"PCM computation failed: {exc}") from exc
     return out.cpu().numpy()
 
 
 def pcm_topk(image1: np.ndarray, image2: np.ndarray, k: int = 2, fft: str = "f64",
-             ctx: Optional[_lib.Context] = None) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+             ctx: Optional[_lib.Context] = None, window: Optional[str] = None
+             ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """``multi_peak_max(pcm(a, b), max_peaks=k)`` fused on the device
     (_translation_computation.py:342-441): rows, cols (int64), vals (float64) in
     descending order, equal values by descending flat index."""
@@ -285,7 +294,7 @@ def pcm_topk(image1: np.ndarray, image2: np.ndarray, k: int = 2, fft: str = "f64
     cols = torch.empty((k,), dtype=torch.int32, device=a.device)
     vals = torch.empty((k,), dtype=torch.float64, device=a.device)
     ctx = ctx or _lib.default_context()
-    check(lib.mistitch_pcm_topk(ctx.handle, ptr(a), w, ptr(b), w, h, w, _fft_flag(fft), int(k),
+    check(lib.mistitch_pcm_topk(ctx.handle, ptr(a), w, ptr(b), w, h, w, _fft_flag(fft, window), int(k),
                                 ptr(rows), ptr(cols), ptr(vals)))
     return rows.cpu().numpy().astype(np.int64), cols.cpu().numpy().astype(np.int64), vals.cpu().numpy()
 

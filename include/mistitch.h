@@ -42,6 +42,13 @@ extern "C" {
 #define MISTITCH_FFT_F32 1u /* complex64 spectra: half the traffic, PCM differs at ~1e-7     */
 #define MISTITCH_REG_SUBPIXEL 2u /* mistitch_register_pairs: add the upsampled-DFT estimate    */
 #define MISTITCH_REG_PEAKS10 4u  /* mistitch_register_pairs: search the 10 best peaks (160 candidates) */
+#define MISTITCH_REG_WINDOW_HANN 8u /* registration, mistitch_pcm*, mistitch_subpixel_shift: multiply both strips
+                                       by a separable symmetric Hann window (numpy.hanning along either axis, in
+                                       float64) before the transforms; the candidate NCCs stay on raw pixels.
+                                       OFF by default: the reference applies no window
+                                       (_translation_computation.py:308-313), so its results need this flag unset;
+                                       smooth scenes whose unwindowed correlation peaks at leakage near (0, 0)
+                                       register with it.  No counterpart in the reference. */
 
 /* fusion modes */
 #define MISTITCH_FUSE_OVERWRITE 0 /* last writer wins, the reference behaviour */

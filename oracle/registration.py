@@ -35,10 +35,18 @@ def is_edge_featureless(edge: np.ndarray, variance_threshold: float = FEATURELES
 # ----------------------------------------------------------------------------
 # a-2  peak correlation matrix                                     tc:282-340
 # ----------------------------------------------------------------------------
-def pcm(strip1: np.ndarray, strip2: np.ndarray) -> np.ndarray:
+def hann_window(shape) -> np.ndarray:
+    """Separable symmetric Hann window ``outer(hanning(h), hanning(w))`` in float64.  NOT reference
+    behaviour (the reference applies no window, tc:308-313): the optional extension's own definition."""
+    h, w = shape
+    return np.outer(np.hanning(h), np.hanning(w))
+
+
+def pcm(strip1: np.ndarray, strip2: np.ndarray, window: Optional[str] = None) -> np.ndarray:
     """ifft2 of the cross-power spectrum normalised by (|.| + eps), real part.
 
-    No window, no mean removal, no padding: a circular correlation.  Raises
+    No window (unless the ``window="hann"`` extension is asked for), no mean removal, no
+    padding: a circular correlation.  Raises
     ValueError for non 2-D / mismatching / non-finite inputs (tc:241-256).
     """
     if strip1.ndim != 2 or strip2.ndim != 2:
@@ -47,8 +55,14 @@ def pcm(strip1: np.ndarray, strip2: np.ndarray) -> np.ndarray:
         raise ValueError(f"Images must have same shape. Got {strip1.shape} and {strip2.shape}")
     if not (np.isfinite(strip1).all() and np.isfinite(strip2).all()):
         raise ValueError("Images contain non-finite values")
-    f1 = np.fft.fft2(np.asarray(strip1, dtype=np.float64))
-    f2 = np.fft.fft2(np.asarray(strip2, dtype=np.float64))
+    a, b = np.asarray(strip1, dtype=np.float64), np.asarray(strip2, dtype=np.float64)
+    if window == "hann":
+        wnd = hann_window(a.shape)
+        a, b = a * wnd, b * wnd
+    elif window is not None:
+        raise ValueError(f"unknown window {window!r}")
+    f1 = np.fft.fft2(a)
+    f2 = np.fft.fft2(b)
     cross = f1 * np.conjugate(f2)
     cross = cross / (np.abs(cross) + PCM_EPS)
     return np.fft.ifft2(cross).real
@@ -363,7 +377,7 @@ def edge_strips(img1: np.ndarray, img2: np.ndarray, direction: str, edge_width: 
 
 
 def compute_single_translation(img1: np.ndarray, img2: np.ndarray, direction: str,
-                               edge_width: int, polish: bool = True
+                               edge_width: int, polish: bool = True, window: Optional[str] = None
                                ) -> Optional[Tuple[float, float, float]]:
     """(ncc, y, x) of img2's origin in img1's frame, or None (featureless / failed)."""
     try:
@@ -375,7 +389,7 @@ def compute_single_translation(img1: np.ndarray, img2: np.ndarray, direction: st
         if is_edge_featureless(e1) or is_edge_featureless(e2):
             return None
         eh, ew = e1.shape
-        corr = pcm(e1, e2)
+        corr = pcm(e1, e2, window)
         yins, xins, _ = multi_peak_max(corr)
         score, y, x = compute_translation(e1, e2, yins, xins, -eh, eh, -ew, ew, n=10, polish=polish)
         return score, y + off_y, x + off_x
@@ -387,7 +401,7 @@ def compute_single_translation(img1: np.ndarray, img2: np.ndarray, direction: st
 # a-14  batch seam                                                 tr:310-378
 # ----------------------------------------------------------------------------
 def register_pairs(tiles: np.ndarray, pair_idx: np.ndarray, directions: Sequence[int],
-                   edge_width: int, polish: bool = True):
+                   edge_width: int, polish: bool = True, window: Optional[str] = None):
     """Serial loop over pairs. ``pair_idx[p] = (i1, i2)``; direction 0=left, 1=top.
 
     Returns (out[P,3] float64 with NaN rows for failed pairs, status[P] int8:
@@ -398,7 +412,7 @@ def register_pairs(tiles: np.ndarray, pair_idx: np.ndarray, directions: Sequence
     status = np.zeros(len(pair_idx), dtype=np.int8)
     for p, (i1, i2) in enumerate(pair_idx):
         r = compute_single_translation(tiles[i1], tiles[i2], "top" if directions[p] else "left",
-                                       edge_width, polish=polish)
+                                       edge_width, polish=polish, window=window)
         if r is None:
             status[p] = 1
         else:
