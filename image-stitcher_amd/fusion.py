@@ -188,28 +188,51 @@ def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_
 # ---- the stitch_region tile loop ---------------------------------------------
 @dataclass
 class TileInfo:
-    """What the reference's AcquisitionMetadata carries for one image file."""
+    """What the reference's AcquisitionMetadata carries for one image file (``fov``: the field-of-view
+    index of the key (t, region, fov, z, channel); parsed from ``{region}_{fov}_{z}_...`` when not given)."""
     filename: str
     x_mm: float
     y_mm: float
     z_level: int
     channel: str
+    fov: Optional[int] = None
+
+    def fov_index(self) -> int:
+        if self.fov is not None:
+            return int(self.fov)
+        import os
+        import re
+        m = re.match(r"^[^_]+_(\d+)_\d+_", os.path.basename(self.filename))
+        if not m:
+            raise ValueError(f"cannot tell the field of view of {self.filename!r}: pass TileInfo.fov")
+        return int(m.group(1))
 
 
 def stitch_region(tiles, infos: Sequence[TileInfo], channel_names: Sequence[str], px_um: float,
                   flatfields: Optional[Dict[int, np.ndarray]] = None, apply_flatfield: bool = False,
                   selected_z: Optional[Sequence[int]] = None, mode: str = "overwrite",
-                  update_progress: Optional[Callable[[int, int], None]] = None):
-    """Device replacement of the non-MIP tile loop of ``Stitcher.stitch_region``
-    (stitcher.py:313-410): returns the 5-D ``(1, C, Z, H, W)`` uint16 CUDA tensor.
+                  update_progress: Optional[Callable[[int, int], None]] = None, apply_mip: bool = False):
+    """Device replacement of the tile loop of ``Stitcher.stitch_region`` (stitcher.py:313-410):
+    returns the 5-D ``(1, C, Z, H, W)`` uint16 CUDA tensor.
 
-    tiles[i] belongs to infos[i]; placement happens in sorted-filename order, the
-    channel index is the position in ``channel_names`` and z levels map to their
-    rank among the selected levels, as in the reference.
+    tiles[i] belongs to infos[i]; ``tiles`` is ``[T, H, W]``, ``[T, 1, H, W]`` (squeezed, stitcher.py:241-251)
+    or ``[T, H, W, 3]`` RGB, whose colours go to the planes ``{base}_R/_G/_B`` of ``channel_names`` with
+    ``base = channel.split("_")[0]`` (stitcher.py:224-240).  Placement happens in sorted-filename order,
+    the plane of a channel is its position in ``channel_names`` (the reference's monochrome_channels) and z
+    levels map to their rank among the selected levels.  ``apply_mip``: the tiles of every (fov, channel)
+    group are projected by their per-pixel maximum and placed at z = 0 at the group's first tile's position;
+    the output then has one z level (stitcher.py:152, 347-385).  ``flatfields`` is keyed by plane index.
     """
     torch = _torch()
     tiles = to_device_u16(tiles)
-    h, w = (int(s) for s in tiles.shape[-2:])
+    rgb = tiles.dim() == 4 and int(tiles.shape[-1]) == 3
+    if tiles.dim() == 4 and not rgb:
+        if int(tiles.shape[1]) != 1:
+            raise ValueError(f"Unexpected tile shape: {tuple(tiles.shape[1:])}")
+        tiles = tiles[:, 0]
+    elif tiles.dim() not in (3, 4):
+        raise ValueError(f"Unexpected tile shape: {tuple(tiles.shape[1:])}")
+    h, w = (int(s) for s in (tiles.shape[1:3] if rgb else tiles.shape[-2:]))
     zs = sorted(set(i.z_level for i in infos)) if selected_z is None else sorted(set(selected_z))
     z_index = {z: k for k, z in enumerate(zs)}
     keep = [i for i in range(len(infos)) if infos[i].z_level in z_index]
@@ -217,20 +240,63 @@ def stitch_region(tiles, infos: Sequence[TileInfo], channel_names: Sequence[str]
     x_min = min(i.x_mm for i in infos)
     y_min = min(i.y_mm for i in infos)
     width, height = output_dimensions([i.x_mm for i in infos], [i.y_mm for i in infos], h, w, px_um)
-    n_c, n_z = len(channel_names), len(zs)
-    yx = np.array([[pixel_offset(infos[i].y_mm, y_min, px_um), pixel_offset(infos[i].x_mm, x_min, px_um)]
-                   for i in order], dtype=np.int32).reshape(-1, 2)
-    cidx = [list(channel_names).index(infos[i].channel) for i in order]
-    plane = np.array([c * n_z + z_index[infos[i].z_level] for c, i in zip(cidx, order)], dtype=np.int32)
+    names = list(channel_names)
+    n_c, n_z = len(names), (1 if apply_mip else len(zs))
+    total = len(order)
+    as_i16 = tiles.view(torch.int16)
+
+    # what gets placed: (source tensor [H, W(, 3)] uint16, info of the position, output z)
+    placed_src, placed_info, placed_z, progress = [], [], [], []
+    if apply_mip:
+        groups: Dict[Tuple[int, str], List[int]] = {}
+        for i in order:
+            groups.setdefault((infos[i].fov_index(), infos[i].channel), []).append(i)
+        done = 0
+        ctx = _lib.default_context()
+        for members in groups.values():
+            idx = torch.as_tensor(np.asarray(members, dtype=np.int64), device=tiles.device)
+            stack = as_i16.index_select(0, idx).view(torch.uint16).contiguous()
+            npx = int(stack[0].numel())
+            out = torch.empty(stack.shape[1:], dtype=torch.int16, device=stack.device).view(torch.uint16)
+            check(lib.mistitch_mip(ctx.handle, ptr(stack), len(members), npx, npx, ptr(out)))
+            placed_src.append(out)
+            placed_info.append(infos[members[0]])
+            placed_z.append(0)
+            progress.append(done)
+            done += len(members)
+        sources = torch.stack([p.view(torch.int16) for p in placed_src]) if placed_src else as_i16[:0]
+    else:
+        idx = torch.as_tensor(np.asarray(order, dtype=np.int64), device=tiles.device)
+        sources = as_i16.index_select(0, idx)
+        placed_info = [infos[i] for i in order]
+        placed_z = [z_index[infos[i].z_level] for i in order]
+        progress = list(range(total))
+
+    # planes: one per mono tile, three per RGB tile (R, G, B placed one after the other, as place_tile does)
+    yx_rows, planes = [], []
+    for info, z in zip(placed_info, placed_z):
+        pos = [pixel_offset(info.y_mm, y_min, px_um), pixel_offset(info.x_mm, x_min, px_um)]
+        if rgb:
+            base = info.channel.split("_")[0]
+            for color in ("R", "G", "B"):
+                yx_rows.append(pos)
+                planes.append(names.index(f"{base}_{color}") * n_z + z)
+        else:
+            yx_rows.append(pos)
+            planes.append(names.index(info.channel) * n_z + z)
+    if rgb:
+        sources = sources.permute(0, 3, 1, 2).contiguous().view(-1, h, w)   # [T, 3, H, W] -> [3T, H, W]
+    yx = np.asarray(yx_rows, dtype=np.int32).reshape(-1, 2)
+    plane = np.asarray(planes, dtype=np.int32)
     ffs = tff = None
     if apply_flatfield and flatfields:
         keys = sorted(flatfields.keys())
         ffs = np.stack([np.asarray(flatfields[k]) for k in keys])
-        tff = np.array([keys.index(c) if c in flatfields else -1 for c in cidx], dtype=np.int32)
-    idx = torch.as_tensor(np.asarray(order, dtype=np.int64), device=tiles.device)
-    ordered = tiles.view(torch.int16).index_select(0, idx).view(torch.uint16)
-    mosaic = fuse_tiles(ordered, yx, plane, n_c * n_z, height, width, flatfields=ffs, tile_ff=tff, mode=mode)
+        cidx = plane // n_z
+        tff = np.array([keys.index(int(c)) if int(c) in flatfields else -1 for c in cidx], dtype=np.int32)
+    mosaic = fuse_tiles(sources.view(torch.uint16), yx, plane, n_c * n_z, height, width, flatfields=ffs, tile_ff=tff,
+                        mode=mode)
     if update_progress is not None:
-        for done in range(len(order)):
-            update_progress(done, len(order))
+        for done in progress:
+            update_progress(done, total)
     return mosaic.view(1, n_c, n_z, height, width)

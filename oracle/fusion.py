@@ -94,6 +94,65 @@ def fuse_overwrite(tiles: np.ndarray, tile_yx: np.ndarray, tile_plane: Sequence[
     return out[0, :, 0]
 
 
+def place_tile(mosaic5d: np.ndarray, tile: np.ndarray, x_pixel: int, y_pixel: int, z_level: int, channel: str,
+               monochrome_channels: Sequence[str], flatfields: Optional[Dict[int, np.ndarray]] = None) -> None:
+    """st:208-253: a 2-D tile goes to its channel's plane; an (H, W, 3) tile to the planes ``{base}_R/_G/_B`` with
+    ``base = channel.split("_")[0]``; a (1, H, W) tile is squeezed.  Flatfields are looked up by plane index
+    (st:255-270)."""
+    def put(plane2d, idx):
+        ff = flatfields.get(idx) if flatfields else None
+        place_single_channel_tile(mosaic5d, plane2d, x_pixel, y_pixel, z_level, idx, ff)
+    if tile.ndim == 2:
+        put(tile, list(monochrome_channels).index(channel))
+    elif tile.ndim == 3:
+        if tile.shape[2] == 3:
+            base = channel.split("_")[0]
+            for i, color in enumerate(["R", "G", "B"]):
+                put(tile[:, :, i], list(monochrome_channels).index(f"{base}_{color}"))
+        elif tile.shape[0] == 1:
+            put(tile[0], list(monochrome_channels).index(channel))
+    else:
+        raise ValueError(f"Unexpected tile shape: {tile.shape}")
+
+
+def stitch_region(tiles: Sequence[np.ndarray], keys: Sequence[Tuple[int, int, str]], filenames: Sequence[str],
+                  x_mm: Sequence[float], y_mm: Sequence[float], monochrome_channels: Sequence[str], px_um: float,
+                  selected_z: Optional[Sequence[int]] = None, apply_mip: bool = False,
+                  flatfields: Optional[Dict[int, np.ndarray]] = None, progress: Optional[list] = None) -> np.ndarray:
+    """The tile loop of Stitcher.stitch_region (st:313-410) over tiles already in memory.
+    ``keys[i] = (fov, z_level, channel)``; iteration order = sorted file names (pa:614-621).
+    Returns the (1, C, Z, H, W) array; Z = 1 with ``apply_mip`` (st:152)."""
+    order = [int(i) for i in placement_order(filenames)]
+    zs = sorted(set(k[1] for k in keys)) if selected_z is None else sorted(set(selected_z))
+    z_index = {z: i for i, z in enumerate(zs)}
+    order = [i for i in order if keys[i][1] in z_index]
+    th, tw = tiles[0].shape[-3:-1] if (tiles[0].ndim == 3 and tiles[0].shape[2] == 3) else tiles[0].shape[-2:]
+    width, height = output_dimensions(list(x_mm), list(y_mm), th, tw, px_um)
+    x_min, y_min = min(x_mm), min(y_mm)
+    out = np.zeros((1, len(monochrome_channels), 1 if apply_mip else len(zs), height, width), dtype=tiles[0].dtype)
+    total, done = len(order), 0
+    if apply_mip:
+        groups: Dict[Tuple[int, str], list] = {}
+        for i in order:
+            groups.setdefault((keys[i][0], keys[i][2]), []).append(i)
+        for (fov, channel), members in groups.items():
+            mip = compute_mip([tiles[i] for i in members])
+            first = members[0]
+            place_tile(out, mip, pixel_offset(x_mm[first], x_min, px_um), pixel_offset(y_mm[first], y_min, px_um), 0,
+                       channel, monochrome_channels, flatfields)
+            if progress is not None:
+                progress.append((done, total))
+            done += len(members)
+    else:
+        for i in order:
+            place_tile(out, tiles[i], pixel_offset(x_mm[i], x_min, px_um), pixel_offset(y_mm[i], y_min, px_um),
+                       z_index[keys[i][1]], keys[i][2], monochrome_channels, flatfields)
+            if progress is not None:
+                progress.append((done, total))
+            done += 1
+    return out
+
+
 # ---- a-12 feather (own specification) --------------------------------------
 def feather_weights(tile_h: int, tile_w: int) -> np.ndarray:
     """Separable linear ramp ``min(y+1, H-y) * min(x+1, W-x)`` as float32 (exact integers)."""

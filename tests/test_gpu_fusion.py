@@ -251,3 +251,64 @@ def test_tiles_sticking_out_on_every_side_are_clipped(fu, mode):
     assert (shifted < 0).any()
     got = _np(fu.fuse_tiles(tiles, shifted, plane, 2, wh, ww, mode=mode))
     assert np.array_equal(got, canvas[:, oy:oy + wh, ox:ox + ww])
+
+
+def _acquisition(seed, rows, cols, th, tw, num_z, channels, rgb=False, lead1=False):
+    """Files R0_{fov}_{z}_{channel}.tiff of an overlapping grid with stage positions in mm at 1000 um per pixel."""
+    rng = np.random.default_rng(seed)
+    names, xs, ys, keys, tiles = [], [], [], [], []
+    for fov in range(rows * cols):
+        r, c = divmod(fov, cols)
+        y, x = r * (th - 9) + int(rng.integers(0, 4)), c * (tw - 13) + int(rng.integers(0, 4))
+        for z in range(num_z):
+            for ch in channels:
+                names.append(f"R0_{fov}_{z}_{ch}.tiff")
+                xs.append(float(x))
+                ys.append(float(y))
+                keys.append((fov, z, ch))
+                shape = (th, tw, 3) if rgb else ((1, th, tw) if lead1 else (th, tw))
+                tiles.append(rng.integers(0, 65536, size=shape).astype(np.uint16))
+    return names, xs, ys, keys, tiles
+
+
+@pytest.mark.parametrize("apply_mip", [False, True])
+@pytest.mark.parametrize("kind", ["mono", "rgb", "lead1"])
+def test_stitch_region_rgb_squeeze_and_mip_match_the_reference_loop(fu, kind, apply_mip):
+    """RGB tiles fan out to the {base}_R/_G/_B planes, (1, H, W) tiles are squeezed, and with apply_mip every
+    (fov, channel) z-stack is projected and placed at z = 0: all against the restated reference loop."""
+    rgb, lead1 = kind == "rgb", kind == "lead1"
+    channels = ["BF_LED_matrix_full"] if rgb else ["Fluorescence_488_nm_Ex", "Fluorescence_561_nm_Ex"]
+    mono = ["BF_R", "BF_G", "BF_B"] if rgb else channels
+    names, xs, ys, keys, tiles = _acquisition(3, 2, 3, 40, 56, 3, channels, rgb=rgb, lead1=lead1)
+    infos = [fu.TileInfo(n, x, y, k[1], k[2]) for n, x, y, k in zip(names, xs, ys, keys)]
+    for selected in (None, [1, 2]):
+        calls, ref_calls = [], []
+        got = _np(fu.stitch_region(np.stack(tiles), infos, mono, 1000.0, selected_z=selected, apply_mip=apply_mip,
+                                   update_progress=lambda d, t: calls.append((d, t))))
+        ref = ofu.stitch_region(tiles, keys, names, xs, ys, mono, 1000.0, selected_z=selected, apply_mip=apply_mip,
+                                progress=ref_calls)
+        assert got.shape == ref.shape
+        assert np.array_equal(got, ref)
+        assert calls == ref_calls
+    # flatfields keyed by plane index, one plane left without
+    ffs = {0: synth.make_flatfield(40, 56, amplitude=0.4), (2 if rgb else 1): synth.make_flatfield(40, 56, amplitude=0.1)}
+    got = _np(fu.stitch_region(np.stack(tiles), infos, mono, 1000.0, flatfields=ffs, apply_flatfield=True, apply_mip=apply_mip))
+    ref = ofu.stitch_region(tiles, keys, names, xs, ys, mono, 1000.0, apply_mip=apply_mip, flatfields=ffs)
+    assert np.array_equal(got, ref)
+
+
+def test_mip_known_answers_of_the_reference_tests(fu):
+    """The arrays of the reference's test_compute_mip (stitcher_test.py:167-249), 3-D tiles included."""
+    t3 = [np.array([[[1, 10, 100], [2, 20, 200]], [[3, 30, 300], [4, 40, 400]]], dtype=np.uint16),
+          np.array([[[5, 15, 105], [6, 25, 205]], [[7, 35, 305], [8, 45, 405]]], dtype=np.uint16)]
+    want = np.array([[[5, 15, 105], [6, 25, 205]], [[7, 35, 305], [8, 45, 405]]])
+    assert np.array_equal(fu.compute_mip(t3), want)
+    assert np.array_equal(fu.compute_mip([np.ones((3, 2), dtype=np.uint16)] * 2), np.ones((3, 2)))
+    assert np.array_equal(fu.compute_mip([np.zeros((2, 2, 3), dtype=np.uint16)] * 2), np.zeros((2, 2, 3)))
+    # a constant-tile acquisition as the reference's fixture writes it: value = fov * num_z + z, so the
+    # projection of a field of view is its highest z level
+    names, x_mm, y_mm, zs, tiles = reference_fixture_grid(2, 2, 50, num_z=3)
+    infos = [fu.TileInfo(n, x, y, z, "DAPI") for n, x, y, z in zip(names, x_mm, y_mm, zs)]
+    im = _np(fu.stitch_region(tiles, infos, ["DAPI"], 20.0, apply_mip=True))
+    assert im.shape == (1, 1, 1, 100, 100)
+    assert im[0, 0, 0, 0, 0] == 2 and im[0, 0, 0, 0, 50] == 5 and im[0, 0, 0, 50, 0] == 8 and im[0, 0, 0, 99, 99] == 11
