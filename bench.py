@@ -502,7 +502,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64" if args.fft == "f64" else "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {cfg['label']}, {part}",
+            "config": {"workload": f"{args.workload}: {cfg['label'].replace('edge_width 256', f'edge_width {edge}')}, {part}",
                        "pairs_in_job": job_pairs, "pairs_on_rank0": n_pairs, "edge_width": edge, "fft": args.fft,
                        "fuse_mode": args.fuse_mode, "mosaic": [ch, mosaic_h, mosaic_w],
                        "mosaic_rows_on_rank0": band_h, "tiles_resident_on_rank0": n_local},

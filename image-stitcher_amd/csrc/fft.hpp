@@ -1,4 +1,5 @@
-// In-LDS power-of-two FFT engine for gfx950 wavefronts (64 lanes).
+// In-LDS FFT engine for gfx950 wavefronts (64 lanes): power-of-two lengths, and (at the end of the file)
+// lengths whose factors are all at most 13.
 //
 // Forward transforms are decimation-in-frequency, in place, natural order in,
 // digit-reversed order out; inverse transforms are the adjoint passes run
@@ -133,6 +134,90 @@ struct Dft {
     }
   }
 };
+
+// cos and sin of 2 pi k / R for the odd prime radices, k = 0 .. (R - 1) / 2 (the other half by symmetry).
+template <int R>
+struct OddRoots;
+template <>
+struct OddRoots<3> {
+  static constexpr double c[2] = {1.0, -0.5};
+  static constexpr double s[2] = {0.0, 0.86602540378443864676};
+};
+template <>
+struct OddRoots<5> {
+  static constexpr double c[3] = {1.0, 0.30901699437494742410, -0.80901699437494742410};
+  static constexpr double s[3] = {0.0, 0.95105651629515357211, 0.58778525229247312917};
+};
+template <>
+struct OddRoots<7> {
+  static constexpr double c[4] = {1.0, 0.62348980185873353053, -0.22252093395631440429, -0.90096886790241912624};
+  static constexpr double s[4] = {0.0, 0.78183148246802980871, 0.97492791218182360702, 0.43388373911755812048};
+};
+template <>
+struct OddRoots<11> {
+  static constexpr double c[6] = {1.0, 0.84125353283118116886, 0.41541501300188642553, -0.14231483827328514044,
+                                  -0.65486073394528506406, -0.95949297361449738989};
+  static constexpr double s[6] = {0.0, 0.54064081745559758210, 0.90963199535451837141, 0.98982144188093273238,
+                                  0.75574957435425828377, 0.28173255684142969771};
+};
+template <>
+struct OddRoots<13> {
+  static constexpr double c[7] = {1.0, 0.88545602565320989590, 0.56806474673115580251, 0.12053668025532305335,
+                                  -0.35460488704253562597, -0.74851074817110109863, -0.97094181742605202716};
+  static constexpr double s[7] = {0.0, 0.46472317204376854566, 0.82298386589365639458, 0.99270887409805399280,
+                                  0.93501624268541482344, 0.66312265824079520238, 0.23931566428755776695};
+};
+template <int R>
+constexpr double odd_root_cos(int k) {
+  return k <= R / 2 ? OddRoots<R>::c[k] : OddRoots<R>::c[R - k];
+}
+template <int R>
+constexpr double odd_root_sin(int k) {
+  return k <= R / 2 ? OddRoots<R>::s[k] : -OddRoots<R>::s[R - k];
+}
+
+// DFT of odd prime length R (complex128) by the symmetry of its roots: with a_k = v_k + v_{R-k} and
+// b_k = v_k - v_{R-k}, output m is v_0 + sum_k cos(2 pi m k / R) a_k -+ i sum_k sin(2 pi m k / R) b_k
+// and output R - m its mirror: (R - 1)^2 / 2 real-by-complex multiply-adds instead of (R - 1)^2
+// complex products, every coefficient an immediate.
+template <int R, bool INV, int M, int K = 1>
+__device__ __forceinline__ void dft_odd_terms(const double2 (&a)[R / 2], const double2 (&b)[R / 2], double2& cr, double2& ci) {
+  if constexpr (K <= R / 2) {
+    constexpr double c = odd_root_cos<R>((M * K) % R), s = odd_root_sin<R>((M * K) % R);
+    cr.x = __builtin_fma(c, a[K - 1].x, cr.x);
+    cr.y = __builtin_fma(c, a[K - 1].y, cr.y);
+    ci.x = __builtin_fma(s, b[K - 1].x, ci.x);
+    ci.y = __builtin_fma(s, b[K - 1].y, ci.y);
+    dft_odd_terms<R, INV, M, K + 1>(a, b, cr, ci);
+  }
+}
+template <int R, bool INV, int M = 1>
+__device__ __forceinline__ void dft_odd_rows(double2 v0, const double2 (&a)[R / 2], const double2 (&b)[R / 2], double2 (&v)[R]) {
+  if constexpr (M <= R / 2) {
+    double2 cr = v0, ci = mk<double>(0.0, 0.0);
+    dft_odd_terms<R, INV, M>(a, b, cr, ci);
+    // forward: cr - i ci at m, cr + i ci at R - m; the inverse swaps them
+    const double2 lo = mk<double>(cr.x + ci.y, cr.y - ci.x), hi = mk<double>(cr.x - ci.y, cr.y + ci.x);
+    v[M] = INV ? hi : lo;
+    v[R - M] = INV ? lo : hi;
+    dft_odd_rows<R, INV, M + 1>(v0, a, b, v);
+  }
+}
+template <int R, bool INV>
+__device__ __forceinline__ void dft_odd(double2 (&v)[R]) {
+  static_assert(R % 2 == 1 && R >= 3, "odd radices only");
+  double2 a[R / 2], b[R / 2];
+  const double2 v0 = v[0];
+  double2 sum = v0;
+#pragma unroll
+  for (int k = 1; k <= R / 2; ++k) {
+    a[k - 1] = cadd(v[k], v[R - k]);
+    b[k - 1] = csub(v[k], v[R - k]);
+    sum = cadd(sum, a[k - 1]);
+  }
+  v[0] = sum;
+  dft_odd_rows<R, INV>(v0, a, b, v);
+}
 
 // Workgroup barrier that orders LDS traffic only.  The transforms communicate through LDS alone,
 // and unlike __syncthreads() this does not wait for global loads a caller has in flight (the
@@ -282,5 +367,90 @@ __device__ __forceinline__ void fft_inverse(cx<T>* buf, const Addr& addr, int nf
     lds_barrier();
   }
 }
+
+// ---- lengths with odd factors ------------------------------------------------------------------
+// The same in-place scheme for a length N = product of radices from {2, 3, 4, 5, 7, 8, 11, 13}
+// (complex128, transforms as columns of a row-major [N][rowstride] matrix, a power-of-two number
+// of them).  Block lengths are no longer powers of two, so butterflies are located by a division
+// (a multiply-high by a precomputed reciprocal) and twiddles come from the whole table of N roots in
+// LDS: the index j d N / n of the d-th twiddle of butterfly j never reaches N, so no reduction either.
+template <int R, bool INV>
+__device__ __forceinline__ void mixed_pass(double2* buf, int rowstride, int lncol, int N, int n, const double2* twN,
+                                           int tid, int nthr) {
+  const int per = N / R, sub = n / R, twstep = N / n;
+  const unsigned magic = sub > 1 ? 0xffffffffu / (unsigned)sub + 1u : 0u;  // exact quotients while g * sub < 2^32
+  const int cmask = (1 << lncol) - 1;
+  for (int w = tid; w < (per << lncol); w += nthr) {
+    const int g = w >> lncol, f = w & cmask;
+    const int blk = sub > 1 ? (int)__umulhi((unsigned)g, magic) : g;
+    const int j = g - blk * sub;
+    double2* at = buf + (blk * n + j) * rowstride + f;
+    const int step = sub * rowstride;
+    double2 v[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) v[m] = at[m * step];
+    if constexpr (!INV) {
+      if constexpr (R & 1)
+        dft_odd<R, false>(v);
+      else
+        Dft<double, R, false>::run(v);
+      if (sub > 1) {
+        const int t = j * twstep;
+#pragma unroll
+        for (int d = 1; d < R; ++d) v[d] = cmul(v[d], twN[t * d]);
+      }
+    } else {
+      if (sub > 1) {
+        const int t = j * twstep;
+#pragma unroll
+        for (int d = 1; d < R; ++d) v[d] = cmulc(v[d], twN[t * d]);
+      }
+      if constexpr (R & 1)
+        dft_odd<R, true>(v);
+      else
+        Dft<double, R, true>::run(v);
+    }
+#pragma unroll
+    for (int m = 0; m < R; ++m) at[m * step] = v[m];
+  }
+}
+
+template <bool INV>
+__device__ __forceinline__ void mixed_dispatch(int radix, double2* buf, int rowstride, int lncol, int N, int n,
+                                               const double2* twN, int tid, int nthr) {
+  switch (radix) {
+    case 13: mixed_pass<13, INV>(buf, rowstride, lncol, N, n, twN, tid, nthr); break;
+    case 11: mixed_pass<11, INV>(buf, rowstride, lncol, N, n, twN, tid, nthr); break;
+    case 8: mixed_pass<8, INV>(buf, rowstride, lncol, N, n, twN, tid, nthr); break;
+    case 7: mixed_pass<7, INV>(buf, rowstride, lncol, N, n, twN, tid, nthr); break;
+    case 5: mixed_pass<5, INV>(buf, rowstride, lncol, N, n, twN, tid, nthr); break;
+    case 4: mixed_pass<4, INV>(buf, rowstride, lncol, N, n, twN, tid, nthr); break;
+    case 3: mixed_pass<3, INV>(buf, rowstride, lncol, N, n, twN, tid, nthr); break;
+    default: mixed_pass<2, INV>(buf, rowstride, lncol, N, n, twN, tid, nthr); break;
+  }
+}
+
+// Forward: natural order in, digit-reversed out.  Returns with the block synchronised.
+__device__ __forceinline__ void mixed_forward(double2* buf, int rowstride, int lncol, const FftPlanDev& plan,
+                                              const double2* twN, int tid, int nthr) {
+  int n = plan.n;
+  for (int i = 0; i < plan.npass; ++i) {
+    mixed_dispatch<false>(plan.radix[i], buf, rowstride, lncol, plan.n, n, twN, tid, nthr);
+    n /= plan.radix[i];
+    lds_barrier();
+  }
+}
+
+// Unnormalised inverse: digit-reversed in, natural out.
+__device__ __forceinline__ void mixed_inverse(double2* buf, int rowstride, int lncol, const FftPlanDev& plan,
+                                              const double2* twN, int tid, int nthr) {
+  int n = 1;
+  for (int i = plan.npass - 1; i >= 0; --i) {
+    n *= plan.radix[i];
+    mixed_dispatch<true>(plan.radix[i], buf, rowstride, lncol, plan.n, n, twN, tid, nthr);
+    lds_barrier();
+  }
+}
+
 
 }  // namespace mistitch

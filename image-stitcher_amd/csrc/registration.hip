@@ -684,7 +684,11 @@ struct CpsUnit {
 // half a CU whatever NT is, so a complex128 pass runs 512 lanes a workgroup: four waves per
 // SIMD instead of two hide the LDS round trip of each radix pass (2.6 instead of 3.1 ms on
 // the 2048 x 256 strips).
-template <typename T, int NT, int MAXR>
+//
+// MIXED: S is not a power of two but a product of radices up to 13 (complex128 only).  The passes
+// are the division-based ones, the twiddles one table of all S roots; rows of the subpixel stage's
+// copy start at row Sr / 2 - S / 2 of Sr = S + (S & 1) rows, the first of which stays empty for odd S.
+template <typename T, int NT, int MAXR, bool MIXED = false>
 __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, const int8_t* status, int pair0, int S, int L,
                                                       int want_transposed, FftPlanDev planS, FftPlanDev planL,
                                                       const CpsUnit* __restrict__ units, int rs, const cx<T>* slabs,
@@ -707,13 +711,25 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
   const int64_t sp = slab_pitch(S);
   const cx<T>* Zs = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L);
   MS_STAMP(1, 0);
-  const Twiddles<T> tw = load_twiddles<T>(buf + S * rs, planS, tid, NT);
+  static_assert(!MIXED || sizeof(T) == 8, "the mixed-radix passes are complex128");
+  Twiddles<T> tw{nullptr, nullptr};
+  cx<T>* twN = buf + S * rs;  // MIXED: all S roots
+  if constexpr (MIXED) {
+    const cx<T>* src = reinterpret_cast<const cx<T>*>(planS.tw);
+    for (int q = tid; q < S; q += NT) twN[q] = src[q];
+  } else {
+    tw = load_twiddles<T>(buf + S * rs, planS, tid, NT);
+  }
   // the short-axis index tables go to LDS once instead of being looked up in memory per cell
-  uint16_t* mposS = reinterpret_cast<uint16_t*>(buf + S * rs + Twiddles<T>::entries(S));
+  uint16_t* mposS = reinterpret_cast<uint16_t*>(buf + S * rs + (MIXED ? S : Twiddles<T>::entries(S)));
   uint16_t* rowS = mposS + S;  // position -> row of the kept spectrum (ascending signed frequency)
   for (int q = tid; q < S; q += NT) {
     mposS[q] = planS.mpos[q];
-    rowS[q] = (uint16_t)((planS.pos2freq[q] + S / 2) & (S - 1));
+    const int f = planS.pos2freq[q];
+    if constexpr (MIXED)
+      rowS[q] = (uint16_t)((f < (S + 1) / 2 ? f : f - S) + (S + (S & 1)) / 2);
+    else
+      rowS[q] = (uint16_t)((f + S / 2) & (S - 1));
   }
   const int lncol = 31 - __builtin_clz(ncol), lna = 31 - __builtin_clz(na);  // 8 or 16 columns: shifts, not divisions
   const int n_elem = S * ncol;
@@ -749,7 +765,10 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
   lds_barrier();
   ColAddr<T> addr{rs};
   MS_STAMP(1, 1);
-  fft_forward<T, MAXR>(buf, addr, ncol, planS, tw, tid, NT);
+  if constexpr (MIXED)
+    mixed_forward(buf, rs, lncol, planS, twN, tid, NT);
+  else
+    fft_forward<T, MAXR>(buf, addr, ncol, planS, tw, tid, NT);
   MS_STAMP(1, 2);
   const bool partner_in_a = mp >= un.a0 && mp < un.a0 + na;
   const int pc = partner_in_a ? (mp - un.a0) : (na + mp - un.b0);
@@ -783,9 +802,18 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
       const int pos = un.a0 + c;
       Rs[(pos / kSlab) * sp + rowS[q] * kSlab + pos % kSlab] = buf[q * rs + c];
     }
+    if constexpr (MIXED) {
+      if ((S & 1) && tid < na) {
+        const int pos = un.a0 + tid;
+        Rs[(pos / kSlab) * sp + pos % kSlab] = mk<T>((T)0, (T)0);
+      }
+    }
     lds_barrier();  // the inverse transform's first pass overwrites cells other lanes copy out here
   }
-  fft_inverse<T, MAXR>(buf, addr, na, planS, tw, tid, NT);
+  if constexpr (MIXED)
+    mixed_inverse(buf, rs, lna, planS, twN, tid, NT);
+  else
+    fft_inverse<T, MAXR>(buf, addr, na, planS, tw, tid, NT);
   MS_STAMP(1, 4);
   // the intermediate spectrum holds the stored columns only, packed in ascending position
   // order: the last pass then reads whole rows contiguously
@@ -1032,6 +1060,7 @@ __device__ __forceinline__ void bluestein_lines(double2* buf, const LineAddr<dou
 // The same with the chirp and filter values a lane needs held in registers (lane tid of an NT-wide
 // workgroup only ever touches elements tid + NT j of a line) and no division in the element loops:
 // for n <= kThreads * kBlueC and M <= kThreads * kBlueH.
+constexpr int kMixedShortThreads = 256;  // radix-13 butterflies: 15 a column of 195, 240 for 16 columns
 constexpr int kGenShortThreads = 512, kGenShortRadix = 8;  // as the power-of-two column pass: more waves, radix-8 plans
 constexpr int kBlueC = 2, kBlueH = 4;
 struct BluesteinRegs {
@@ -2372,6 +2401,24 @@ __global__ void k_peaks_to_arrays(const Peak* peaks, int k, int img_w, int32_t* 
 // ---------------------------------------------------------------------------
 static bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
+// The passes of a length with odd factors: its odd prime factors (each at most 13) in descending
+// order, then the power of two that is left in radices of at most 8.  False when a larger prime
+// divides n or the passes would be more than six.
+static bool mixed_radices(int n, std::vector<int>* out) {
+  out->clear();
+  for (int r : {13, 11, 7, 5, 3})
+    while (n % r == 0) {
+      out->push_back(r);
+      n /= r;
+    }
+  if (n & (n - 1)) return false;
+  int lg = 0;
+  while ((1 << lg) < n) ++lg;
+  if (lg % 3) out->push_back(1 << (lg % 3));
+  for (int i = 0; i < lg / 3; ++i) out->push_back(8);
+  return !out->empty() && out->size() <= 6;
+}
+
 static int build_plan(mistitch_ctx* ctx, int n, bool f64, FftPlanDev* out, int max_radix = 16) {
   const long long key = ((long long)n * 2 + (f64 ? 1 : 0)) * 32 + max_radix;
   auto it = ctx->plans.find(key);
@@ -2383,20 +2430,23 @@ static int build_plan(mistitch_ctx* ctx, int n, bool f64, FftPlanDev* out, int m
   ph.dev.n = n;
   // remainder radix first, then 16s: the last (largest) radix sets how many
   // adjacent storage positions share their low frequency digits.
-  int lg = 0;
-  while ((1 << lg) < n) ++lg;
   int np = 0;
-  const int lr = max_radix >= 16 ? 4 : (max_radix >= 8 ? 3 : 2);
-  if (lg % lr) ph.dev.radix[np++] = 1 << (lg % lr);
-  for (int i = 0; i < lg / lr; ++i) ph.dev.radix[np++] = 1 << lr;
+  if (is_pow2(n)) {
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    const int lr = max_radix >= 16 ? 4 : (max_radix >= 8 ? 3 : 2);
+    if (lg % lr) ph.dev.radix[np++] = 1 << (lg % lr);
+    for (int i = 0; i < lg / lr; ++i) ph.dev.radix[np++] = 1 << lr;
+  } else {
+    std::vector<int> radices;
+    MS_REQUIRE(mixed_radices(n, &radices), MISTITCH_ERR_UNSUPPORTED, "cannot factor FFT length %d into radices up to 13", n);
+    for (int r : radices) ph.dev.radix[np++] = r;
+  }
   ph.dev.npass = np;
   {
     long long prod = 1;
     for (int i = 0; i < np; ++i) prod *= ph.dev.radix[i];
     MS_REQUIRE(prod == n && np <= 6, MISTITCH_ERR_UNSUPPORTED, "cannot factor FFT length %d", n);
-    for (int i = 0; i < np; ++i)
-      MS_REQUIRE(ph.dev.radix[i] == 2 || ph.dev.radix[i] == 4 || ph.dev.radix[i] == 8 || ph.dev.radix[i] == 16,
-                 MISTITCH_ERR_UNSUPPORTED, "bad radix %d for FFT length %d", ph.dev.radix[i], n);
   }
   std::vector<uint16_t> pos2freq(n), freq2pos(n), mpos(n);
   for (int pos = 0; pos < n; ++pos) {
@@ -2512,7 +2562,8 @@ static bool build_units(const std::vector<uint16_t>& mpos, int L, int C, std::ve
 
 struct ShapeCfg {
   int S, L;
-  bool gen_short;   // the short side is not a power of two: its transforms run by chirp-z (complex128 only)
+  bool gen_short;   // the short side is not a power of two (complex128 only)
+  bool mixed_short; // ... but a product of radices up to 13: mixed-radix passes on planS; chirp-z on gpS otherwise
   GenPlanDev gpS;   // the chirp-z plan of the short axis then (planS unused)
   FftPlanDev planS, planL;
   int C;       // columns per block of the column pass (LDS rows hold 2C)
@@ -2556,8 +2607,14 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   cfg->S = S;
   cfg->L = L;
   cfg->gen_short = gen_short;
+  std::vector<int> short_radices;
+  const bool mixed = gen_short && mixed_radices(S, &short_radices);
+  cfg->mixed_short = mixed;
   int rc;
-  if (gen_short) {
+  if (mixed) {
+    rc = build_plan(ctx, S, true, &cfg->planS);
+    memset(&cfg->gpS, 0, sizeof(cfg->gpS));
+  } else if (gen_short) {
     rc = build_gen_plan(ctx, S, &cfg->gpS, kGenShortRadix);
     memset(&cfg->planS, 0, sizeof(cfg->planS));
   } else {
@@ -2574,9 +2631,10 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   std::vector<CpsUnit> units;
   std::vector<uint16_t> stored_pos, mirror_fill;
   // (chirp-z columns are lines of M >= 2S - 1 elements: 76 KiB still leaves room for two blocks per CU)
-  const size_t col_bytes = gen_short ? line_bytes<double>(cfg->gpS.M) : (size_t)S * esz;
-  const size_t col_budget = gen_short ? 76 * 1024 : kLdsBudget;
-  int C = gen_short ? 8 : 16;
+  const bool chirp = gen_short && !mixed;
+  const size_t col_bytes = chirp ? line_bytes<double>(cfg->gpS.M) : (size_t)S * esz;
+  const size_t col_budget = chirp ? 76 * 1024 : kLdsBudget;
+  int C = chirp ? 8 : 16;
   for (; C >= 1; C >>= 1) {
     if (C > L) continue;
     if (C > 1 && col_bytes * 2 * C > col_budget) continue;
@@ -2584,7 +2642,9 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   }
   MS_REQUIRE(C >= 1, MISTITCH_ERR_UNSUPPORTED, "no column-pass decomposition for long side %d", L);
   cfg->C = C;
-  if (gen_short)
+  if (mixed)
+    cfg->lds_cps = ((size_t)S * 2 * C + S) * esz + ((size_t)S * 4 + 15) / 16 * 16;  // columns, all S roots, two index tables
+  else if (gen_short)
     cfg->lds_cps = col_bytes * 2 * C + (size_t)Twiddles<double>::entries(cfg->gpS.M) * 16;
   else
     cfg->lds_cps = ((size_t)S * 2 * C + (f64 ? Twiddles<double>::entries(S) : Twiddles<float>::entries(S))) * esz +
@@ -3058,7 +3118,14 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
   const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
   bool column_pass_done = false;
   if constexpr (std::is_same<T, double>::value) {
-    if (cfg.gen_short) {
+    if (cfg.mixed_short) {
+      constexpr int kNT = kMixedShortThreads;
+      if ((rc = allow_lds(ctx, k_fft_short_cps<double, kNT, 8, true>, cfg.lds_cps))) return rc;
+      MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<double, kNT, 8, true>), dim3(cfg.n_units, n), dim3(kNT), cfg.lds_cps,
+                ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec,
+                eps, ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
+      column_pass_done = true;
+    } else if (cfg.gen_short) {
       if ((rc = allow_lds(ctx, k_fft_short_cps_gen, cfg.lds_cps))) return rc;
       MS_LAUNCH(ctx, "k_fft_short_cps", k_fft_short_cps_gen, dim3(cfg.n_units, n), dim3(kGenShortThreads), cfg.lds_cps, ws.desc, status,
                 pair0, cfg.S, cfg.L, want_transposed, cfg.gpS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps,

@@ -45,7 +45,12 @@ def test_unsupported_shape_is_an_error(reg):
 
 
 @pytest.mark.parametrize("shape", [(50, 300), (195, 512), (97, 101), (64, 300), (30, 1000), (7, 9), (130, 64),
-                                   (100, 256), (45, 1024), (2048, 195), (3, 64), (9, 8)])
+                                   (100, 256), (45, 1024), (2048, 195), (3, 64), (9, 8),
+                                   # short sides that factor into radices up to 13 (mixed-radix passes) ...
+                                   (77, 128), (91, 256), (208, 256), (176, 512), (6, 32), (768, 1024), (1000, 1024),
+                                   (169, 256), (14, 16),
+                                   # ... and ones with a larger prime factor (chirp-z)
+                                   (34, 64), (257, 512)])
 def test_pcm_of_any_size(reg, shape):
     """PCM and its ranking for strips whose sides are not powers of two (primes, odd, tall)."""
     h, w = shape
