@@ -471,6 +471,17 @@ def main():
     mpix_per_s = mpix_per_step * args.steps / t_fuse
     fuse_gbs = fuse_bytes * args.steps / t_fuse / 1e9            # this rank's band / the slowest rank's time
     reg_gbs = n_pairs * reg_bytes_per_pair * args.steps / t_reg / 1e9
+    # the bytes the registration passes really move per pair: every kernel's inputs read once and outputs written
+    # once (the transform of a strip pair does not fit on chip: 2 x 8 MiB complex128 round trips through HBM)
+    stored_cols = tile // 2 + 8                                   # columns of the half spectrum the column pass keeps
+    pass_bytes_per_pair = dict(
+        stage=2 * strip_px * 4 if ffs is not None else strip_px * 4,          # strips in and out (left pairs only without a flatfield)
+        fft_long_fwd=2 * strip_px * 2 + strip_px * cplx,
+        fft_short_cps=strip_px * cplx + stored_cols * edge * cplx,
+        fft_long_inv=stored_cols * edge * cplx,
+        ncc=2 * strip_px * 2)
+    pass_total = sum(pass_bytes_per_pair.values())
+    pass_gbs = n_pairs * pass_total * args.steps / t_reg / 1e9
     if side:
         mpix_per_s_other = mpix_per_step * args.steps / t_fuse_other
         fuse_gbs_other = fuse_bytes_by_mode[other_mode] * args.steps / t_fuse_other / 1e9
@@ -512,7 +523,14 @@ def main():
                              "roofline_whole_path": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                                      "achieved": round(reg_gbs, 1), "frac": round(reg_gbs / HBM_PEAK_GBS, 4),
                                                      "algorithmic_bytes_per_pair": reg_bytes_per_pair,
-                                                     "per": "GPU (rank 0's pairs / the slowest rank's time)"}},
+                                                     "per": "GPU (rank 0's pairs / the slowest rank's time)"},
+                             "roofline_pass_model": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                                     "achieved": round(pass_gbs, 1), "frac": round(pass_gbs / HBM_PEAK_GBS, 4),
+                                                     "bytes_per_pair": int(pass_total),
+                                                     "bytes_per_pair_by_pass": {k: int(v) for k, v in pass_bytes_per_pair.items()},
+                                                     "what": "inputs read once and outputs written once by every kernel of the "
+                                                             "pipeline (the 2-D transform of a strip pair makes two round trips "
+                                                             "through HBM); the whole-path figure above counts the two strips only"}},
             "fusion": {"metric": "fused_mosaic_MPix_per_sec", "value": round(mpix_per_s, 1), "unit": "MPix/s",
                        "dtype": "u16", "mode": args.fuse_mode, "ms_per_step": round(1e3 * t_fuse / args.steps, 3),
                        "roofline": {"bound": "hbm", "achieved": round(fuse_gbs, 1), "peak": HBM_PEAK_GBS,

@@ -368,6 +368,119 @@ __device__ __forceinline__ void fft_inverse(cx<T>* buf, const Addr& addr, int nf
   }
 }
 
+// ---- transforms whose data enters from, or leaves to, global memory ---------------------------
+// The first forward pass can take its inputs straight from global memory and the last inverse pass can
+// hand its outputs straight to global memory: the data then crosses LDS once less in each direction
+// (the column pass of the registration is bound by LDS traffic, not by HBM).
+//
+// First pass of a forward transform (sub-block length n = N): load(f, i) returns element i of
+// transform f.  Two work items per lane and trip, all their loads issued before the first butterfly.
+// barrier_first: the twiddle tables were written to LDS by this workgroup and not yet synchronised;
+// the barrier then comes after the first trip's loads have been issued.  Every lane runs the same
+// number of trips (the barrier is inside the loop).
+template <typename T, int R, class Addr, class Load>
+__device__ __forceinline__ void fft_first_pass_from(cx<T>* buf, const Addr& addr, int nfft, int N, const Twiddles<T>& tw,
+                                                    int tid, int nthr, bool barrier_first, Load load) {
+  const int per = N / R;  // butterflies per transform; also the element stride inside one
+  const int total = nfft * per;
+  constexpr int kItems = 2;
+  for (int base = 0; base < total; base += kItems * nthr) {
+    cx<T> v[kItems][R];
+    int f[kItems], j[kItems];
+#pragma unroll
+    for (int u = 0; u < kItems; ++u) {
+      const int w = min(base + u * nthr + tid, total - 1);  // clamp: never branch around a load
+      addr.split(w, nfft, per, f[u], j[u]);
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[u][m] = load(f[u], j[u] + m * per);
+    }
+    if (barrier_first && base == 0) lds_barrier();
+#pragma unroll
+    for (int u = 0; u < kItems; ++u) {
+      if (base + u * nthr + tid < total) {
+        Dft<T, R, false>::run(v[u]);
+        if (per > 1) {
+          cx<T> pw[R];
+          twiddle_powers<T, R>(tw.get(j[u]), pw);
+#pragma unroll
+          for (int d = 1; d < R; ++d) v[u][d] = cmul(v[u][d], pw[d]);
+        }
+#pragma unroll
+        for (int m = 0; m < R; ++m) buf[addr(f[u], j[u] + m * per)] = v[u][m];
+      }
+    }
+  }
+  if (barrier_first && total <= 0) lds_barrier();
+}
+
+// Forward transform whose first pass reads global memory through load(f, i).  Returns with the
+// block synchronised.  tables_unsynchronised: see fft_first_pass_from.
+template <typename T, int MAXR = 16, class Addr, class Load>
+__device__ __forceinline__ void fft_forward_from(cx<T>* buf, const Addr& addr, int nfft, const FftPlanDev& plan,
+                                                 const Twiddles<T>& tw, int tid, int nthr, bool tables_unsynchronised,
+                                                 Load load) {
+  switch (plan.radix[0]) {
+    case 16:
+      if constexpr (MAXR >= 16) fft_first_pass_from<T, 16>(buf, addr, nfft, plan.n, tw, tid, nthr, tables_unsynchronised, load);
+      break;
+    case 8: fft_first_pass_from<T, 8>(buf, addr, nfft, plan.n, tw, tid, nthr, tables_unsynchronised, load); break;
+    case 4: fft_first_pass_from<T, 4>(buf, addr, nfft, plan.n, tw, tid, nthr, tables_unsynchronised, load); break;
+    default: fft_first_pass_from<T, 2>(buf, addr, nfft, plan.n, tw, tid, nthr, tables_unsynchronised, load); break;
+  }
+  lds_barrier();
+  int n = plan.n / plan.radix[0];
+  for (int i = 1; i < plan.npass; ++i) {
+    fft_dispatch<T, false, MAXR>(plan.radix[i], buf, addr, nfft, plan.n, n, tw, tid, nthr);
+    n /= plan.radix[i];
+    lds_barrier();
+  }
+}
+
+// Last pass of an inverse transform (sub-block length n = N): store(f, i, value) takes element i of
+// transform f.
+template <typename T, int R, class Addr, class Store>
+__device__ __forceinline__ void fft_last_pass_to(const cx<T>* buf, const Addr& addr, int nfft, int N, const Twiddles<T>& tw,
+                                                 int tid, int nthr, Store store) {
+  const int per = N / R;
+  for (int w = tid; w < nfft * per; w += nthr) {
+    int f, j;
+    addr.split(w, nfft, per, f, j);
+    cx<T> v[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) v[m] = buf[addr(f, j + m * per)];
+    if (per > 1) {
+      cx<T> pw[R];
+      twiddle_powers<T, R>(tw.get(j), pw);
+#pragma unroll
+      for (int d = 1; d < R; ++d) v[d] = cmulc(v[d], pw[d]);
+    }
+    Dft<T, R, true>::run(v);
+#pragma unroll
+    for (int m = 0; m < R; ++m) store(f, j + m * per, v[m]);
+  }
+}
+
+// Unnormalised inverse transform whose last pass hands its results to store(f, i, value) instead of
+// writing them back to LDS.  No barrier after the last pass: it writes no LDS.
+template <typename T, int MAXR = 16, class Addr, class Store>
+__device__ __forceinline__ void fft_inverse_to(cx<T>* buf, const Addr& addr, int nfft, const FftPlanDev& plan,
+                                               const Twiddles<T>& tw, int tid, int nthr, Store store) {
+  int n = 1;
+  for (int i = plan.npass - 1; i >= 1; --i) {
+    n *= plan.radix[i];
+    fft_dispatch<T, true, MAXR>(plan.radix[i], buf, addr, nfft, plan.n, n, tw, tid, nthr);
+    lds_barrier();
+  }
+  switch (plan.radix[0]) {
+    case 16:
+      if constexpr (MAXR >= 16) fft_last_pass_to<T, 16>(buf, addr, nfft, plan.n, tw, tid, nthr, store);
+      break;
+    case 8: fft_last_pass_to<T, 8>(buf, addr, nfft, plan.n, tw, tid, nthr, store); break;
+    case 4: fft_last_pass_to<T, 4>(buf, addr, nfft, plan.n, tw, tid, nthr, store); break;
+    default: fft_last_pass_to<T, 2>(buf, addr, nfft, plan.n, tw, tid, nthr, store); break;
+  }
+}
+
 // ---- lengths with odd factors ------------------------------------------------------------------
 // The same in-place scheme for a length N = product of radices from {2, 3, 4, 5, 7, 8, 11, 13}
 // (complex128, transforms as columns of a row-major [N][rowstride] matrix, a power-of-two number

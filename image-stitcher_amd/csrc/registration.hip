@@ -737,38 +737,54 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
   // lane's cells is the same on every trip (na is a power of two no larger than NT)
   const int mp = planL.mpos[un.a0 + (tid & (na - 1))];
   const int col0 = pos2stored[un.a0];
-  {
-    // Lane tid's k-th element is e = tid + k NT: the same column, NT / ncol rows further down, so
-    // one per-lane offset and a uniform step address every load and every LDS write.
-    constexpr int U = 4096 / NT;  // loads in flight per lane before the first LDS write
-    const int e_t = min(tid, n_elem - 1);
-    const int c_t = e_t & (ncol - 1);
-    const int pos_t = c_t < na ? un.a0 + c_t : un.b0 + (c_t - na);
-    const cx<T>* src = Zs + (pos_t / kSlab) * sp + (e_t >> lncol) * kSlab + pos_t % kSlab;
-    const int src_step = (NT >> lncol) * kSlab;
-    cx<T>* dst = buf + (tid >> lncol) * rs + (tid & (ncol - 1));
-    const int dst_step = (NT >> lncol) * rs;
-    for (int e0 = tid, k0 = 0; e0 < n_elem; e0 += NT * U, k0 += U) {
-      cx<T> r[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) r[u] = src[e0 + u * NT < n_elem ? (k0 + u) * src_step : 0];  // never branch around a load
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        MS_PIN(r[u].x);
-        MS_PIN(r[u].y);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (e0 + u * NT < n_elem) dst[(k0 + u) * dst_step] = r[u];
-    }
-  }
-  lds_barrier();
   ColAddr<T> addr{rs};
-  MS_STAMP(1, 1);
-  if constexpr (MIXED)
-    mixed_forward(buf, rs, lncol, planS, twN, tid, NT);
-  else
-    fft_forward<T, MAXR>(buf, addr, ncol, planS, tw, tid, NT);
+  // complex128 power-of-two columns: the first radix pass reads the slabs itself and the last one writes the
+  // spectrum itself (2.57 -> 2.38 ms on the 2048 x 256 strips; the pass is bound by LDS traffic).  complex64
+  // columns lose by it (1.45 -> 2.37 ms: 8-byte accesses, sixteen to a radix-16 butterfly) and keep the
+  // separate copy loops.
+  constexpr bool kFuseFirst = !MIXED && sizeof(T) == 8;
+  constexpr bool kFuseLast = kFuseFirst;
+  if constexpr (!kFuseFirst) {
+    {
+      // Lane tid's k-th element is e = tid + k NT: the same column, NT / ncol rows further down, so
+      // one per-lane offset and a uniform step address every load and every LDS write.
+      constexpr int U = 4096 / NT;  // loads in flight per lane before the first LDS write
+      const int e_t = min(tid, n_elem - 1);
+      const int c_t = e_t & (ncol - 1);
+      const int pos_t = c_t < na ? un.a0 + c_t : un.b0 + (c_t - na);
+      const cx<T>* src = Zs + (pos_t / kSlab) * sp + (e_t >> lncol) * kSlab + pos_t % kSlab;
+      const int src_step = (NT >> lncol) * kSlab;
+      cx<T>* dst = buf + (tid >> lncol) * rs + (tid & (ncol - 1));
+      const int dst_step = (NT >> lncol) * rs;
+      for (int e0 = tid, k0 = 0; e0 < n_elem; e0 += NT * U, k0 += U) {
+        cx<T> r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) r[u] = src[e0 + u * NT < n_elem ? (k0 + u) * src_step : 0];  // never branch around a load
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          MS_PIN(r[u].x);
+          MS_PIN(r[u].y);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (e0 + u * NT < n_elem) dst[(k0 + u) * dst_step] = r[u];
+      }
+    }
+    lds_barrier();
+    MS_STAMP(1, 1);
+    if constexpr (MIXED)
+      mixed_forward(buf, rs, lncol, planS, twN, tid, NT);
+    else
+      fft_forward<T, MAXR>(buf, addr, ncol, planS, tw, tid, NT);
+  } else {
+    // the first radix pass takes the columns straight from the slabs: lanes of one row read its 2C
+    // columns (two runs of 128 or 64 bytes), and nothing is written to LDS that the pass would only read back
+    MS_STAMP(1, 1);
+    fft_forward_from<T, MAXR>(buf, addr, ncol, planS, tw, tid, NT, true, [&](int c, int q) {
+      const int pos = c < na ? un.a0 + c : un.b0 + (c - na);
+      return Zs[(pos / kSlab) * sp + q * kSlab + pos % kSlab];
+    });
+  }
   MS_STAMP(1, 2);
   const bool partner_in_a = mp >= un.a0 && mp < un.a0 + na;
   const int pc = partner_in_a ? (mp - un.a0) : (na + mp - un.b0);
@@ -810,16 +826,23 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
     }
     lds_barrier();  // the inverse transform's first pass overwrites cells other lanes copy out here
   }
-  if constexpr (MIXED)
-    mixed_inverse(buf, rs, lna, planS, twN, tid, NT);
-  else
-    fft_inverse<T, MAXR>(buf, addr, na, planS, tw, tid, NT);
-  MS_STAMP(1, 4);
   // the intermediate spectrum holds the stored columns only, packed in ascending position
   // order: the last pass then reads whole rows contiguously
-  for (int e = tid; e < S * na; e += NT) {
-    const int s = e >> lna, c = e & (na - 1);
-    Z[(int64_t)s * Lp + col0 + c] = buf[s * rs + c];
+  if constexpr (!kFuseLast) {
+    if constexpr (MIXED)
+      mixed_inverse(buf, rs, lna, planS, twN, tid, NT);
+    else
+      fft_inverse<T, MAXR>(buf, addr, na, planS, tw, tid, NT);
+    MS_STAMP(1, 4);
+    for (int e = tid; e < S * na; e += NT) {
+      const int s = e >> lna, c = e & (na - 1);
+      Z[(int64_t)s * Lp + col0 + c] = buf[s * rs + c];
+    }
+  } else {
+    // the last radix pass stores its results itself (the na columns of a row are one run of 128 or 64 bytes)
+    fft_inverse_to<T, MAXR>(buf, addr, na, planS, tw, tid, NT,
+                            [&](int c, int q, cx<T> v) { Z[(int64_t)q * Lp + col0 + c] = v; });
+    MS_STAMP(1, 4);
   }
   MS_STAMP(1, 5);
 }
@@ -856,6 +879,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
     constexpr int U = 8;  // two loads per element: 16 in flight per lane
     for (int e0 = tid; e0 < NF * n_stored; e0 += kThreads * U) {
       cx<T> g1[U], g2[U];
+      // the positions the values go to are looked up with the values, not after them: one memory round trip, not two
+      uint16_t at_pos[U], at_mir[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int e = min(e0 + u * kThreads, NF * n_stored - 1);  // clamp, do not branch around the loads
@@ -863,6 +888,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
         // lines past the last one (odd S, or a last block that is not full) read the last line and count as zero
         g1[u] = Z[(int64_t)min(s0 + 2 * f, S - 1) * Lp + i];
         g2[u] = Z[(int64_t)min(s0 + 2 * f + 1, S - 1) * Lp + i];
+        at_pos[u] = stored_pos[i];
+        at_mir[u] = mirror_fill[i];
       }
       if (pair_status != MISTITCH_PAIR_OK || d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed))
         return;  // the same for every lane of the workgroup
@@ -875,8 +902,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       for (int u = 0; u < U; ++u) {
         const int e = e0 + u * kThreads;
         if (e < NF * n_stored) {
-          const int f = NF == 1 ? 0 : e / n_stored, i = e - f * n_stored;
-          const int pos = stored_pos[i], mir = mirror_fill[i];
+          const int f = NF == 1 ? 0 : e / n_stored;
+          const int pos = at_pos[u], mir = at_mir[u];
           if (s0 + 2 * f >= S) g1[u] = mk<T>((T)0, (T)0);
           if (s0 + 2 * f + 1 >= S) g2[u] = mk<T>((T)0, (T)0);
           buf[addr(f, pos)] = mk<T>(g1[u].x - g2[u].y, g1[u].y + g2[u].x);  // g1 + i g2
@@ -887,7 +914,10 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   }
   __syncthreads();
   MS_STAMP(2, 1);
-  fft_inverse<T, kLongMaxRadix<T>>(buf, addr, NF, planL, tw, tid, kThreads);
+  // The production case (two peaks, no PCM plane wanted) ranks the values as the last radix pass produces
+  // them, in registers: they are never written back to LDS and read again.
+  const bool rank_in_last_pass = k > 0 && k <= 2 && pcm_out == nullptr;
+  if (!rank_in_last_pass) fft_inverse<T, kLongMaxRadix<T>>(buf, addr, NF, planL, tw, tid, kThreads);
   MS_STAMP(2, 2);
   const double scale = 1.0 / ((double)S * (double)L);
   if (pcm_out != nullptr) {
@@ -929,9 +959,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       k1 = gt1 ? key : k1;
     };
     const bool want_abs = partial_abs != nullptr;
-    for (int e = tid; e < NF * L; e += kThreads) {
-      const int f = e >> lL, l = e & (L - 1);
-      const cx<T> v = buf[addr(f, l)];
+    auto take = [&](int f, int l, cx<T> v) {
       const int s = s0 + 2 * f;
       const int key0 = d.transposed ? l * S + s : s * L + l;
       const int key1 = d.transposed ? key0 + 1 : key0 + L;
@@ -946,6 +974,14 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
         const bool t1 = have1 & first_better(a1v, key1, ba.val, ba.key);
         ba.val = t1 ? a1v : ba.val;
         ba.key = t1 ? key1 : ba.key;
+      }
+    };
+    if (rank_in_last_pass) {
+      fft_inverse_to<T, kLongMaxRadix<T>>(buf, addr, NF, planL, tw, tid, kThreads, take);
+    } else {
+      for (int e = tid; e < NF * L; e += kThreads) {
+        const int f = e >> lL, l = e & (L - 1);
+        take(f, l, buf[addr(f, l)]);
       }
     }
     ba.loc = ba.key >= 0 ? 0 : -1;

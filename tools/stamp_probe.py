@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic: phase durations of the FFT kernels from in-kernel wall-clock stamps (needs tools/variant_stamps.so)."""
+"""Diagnostic: phase durations of the FFT kernels from in-kernel wall-clock stamps (needs tools/variants/stamps.so, built by tools/build_reg_variant.sh stamps -DMS_STAMPS)."""
 import ctypes as C
 import os
 import sys
