@@ -528,6 +528,70 @@ __device__ __forceinline__ void mixed_pass(double2* buf, int rowstride, int lnco
   }
 }
 
+// The same pass with its inputs taken through in(f, i) and its results handed to out(f, i, value)
+// (f the column, i the element): the first forward pass reads global memory and the last inverse pass
+// writes it, as fft_first_pass_from / fft_last_pass_to do for the power-of-two lengths.  Every lane runs the
+// same number of trips; with barrier_first the workgroup synchronises once, after the first trip's inputs have
+// been requested (the table of roots was written to LDS by this workgroup just before).
+template <int R, bool INV, class In, class Out>
+__device__ __forceinline__ void mixed_pass_io(int lncol, int N, int n, const double2* twN, int tid, int nthr,
+                                              bool barrier_first, In in, Out out) {
+  const int per = N / R, sub = n / R, twstep = N / n;
+  const unsigned magic = sub > 1 ? 0xffffffffu / (unsigned)sub + 1u : 0u;
+  const int cmask = (1 << lncol) - 1, total = per << lncol;
+  for (int w0 = 0; w0 < total; w0 += nthr) {
+    const int w = min(w0 + tid, total - 1);  // clamp: never branch around a load
+    const int g = w >> lncol, f = w & cmask;
+    const int blk = sub > 1 ? (int)__umulhi((unsigned)g, magic) : g;
+    const int j = g - blk * sub;
+    const int base = blk * n + j;
+    double2 v[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) v[m] = in(f, base + m * sub);
+    if (barrier_first && w0 == 0) lds_barrier();
+    if (w0 + tid < total) {
+      if constexpr (!INV) {
+        if constexpr (R & 1)
+          dft_odd<R, false>(v);
+        else
+          Dft<double, R, false>::run(v);
+        if (sub > 1) {
+          const int t = j * twstep;
+#pragma unroll
+          for (int d = 1; d < R; ++d) v[d] = cmul(v[d], twN[t * d]);
+        }
+      } else {
+        if (sub > 1) {
+          const int t = j * twstep;
+#pragma unroll
+          for (int d = 1; d < R; ++d) v[d] = cmulc(v[d], twN[t * d]);
+        }
+        if constexpr (R & 1)
+          dft_odd<R, true>(v);
+        else
+          Dft<double, R, true>::run(v);
+      }
+#pragma unroll
+      for (int m = 0; m < R; ++m) out(f, base + m * sub, v[m]);
+    }
+  }
+}
+
+template <bool INV, class In, class Out>
+__device__ __forceinline__ void mixed_dispatch_io(int radix, int lncol, int N, int n, const double2* twN, int tid, int nthr,
+                                                  bool barrier_first, In in, Out out) {
+  switch (radix) {
+    case 13: mixed_pass_io<13, INV>(lncol, N, n, twN, tid, nthr, barrier_first, in, out); break;
+    case 11: mixed_pass_io<11, INV>(lncol, N, n, twN, tid, nthr, barrier_first, in, out); break;
+    case 8: mixed_pass_io<8, INV>(lncol, N, n, twN, tid, nthr, barrier_first, in, out); break;
+    case 7: mixed_pass_io<7, INV>(lncol, N, n, twN, tid, nthr, barrier_first, in, out); break;
+    case 5: mixed_pass_io<5, INV>(lncol, N, n, twN, tid, nthr, barrier_first, in, out); break;
+    case 4: mixed_pass_io<4, INV>(lncol, N, n, twN, tid, nthr, barrier_first, in, out); break;
+    case 3: mixed_pass_io<3, INV>(lncol, N, n, twN, tid, nthr, barrier_first, in, out); break;
+    default: mixed_pass_io<2, INV>(lncol, N, n, twN, tid, nthr, barrier_first, in, out); break;
+  }
+}
+
 template <bool INV>
 __device__ __forceinline__ void mixed_dispatch(int radix, double2* buf, int rowstride, int lncol, int N, int n,
                                                const double2* twN, int tid, int nthr) {
@@ -563,6 +627,37 @@ __device__ __forceinline__ void mixed_inverse(double2* buf, int rowstride, int l
     mixed_dispatch<true>(plan.radix[i], buf, rowstride, lncol, plan.n, n, twN, tid, nthr);
     lds_barrier();
   }
+}
+
+// Forward transform whose first pass takes its inputs through load(f, i) (global memory); tables_unsynchronised:
+// the roots were written to LDS by this workgroup and no barrier has followed yet.
+template <class Load>
+__device__ __forceinline__ void mixed_forward_from(double2* buf, int rowstride, int lncol, const FftPlanDev& plan,
+                                                   const double2* twN, int tid, int nthr, bool tables_unsynchronised,
+                                                   Load load) {
+  mixed_dispatch_io<false>(plan.radix[0], lncol, plan.n, plan.n, twN, tid, nthr, tables_unsynchronised, load,
+                           [&](int f, int i, double2 v) { buf[i * rowstride + f] = v; });
+  lds_barrier();
+  int n = plan.n / plan.radix[0];
+  for (int i = 1; i < plan.npass; ++i) {
+    mixed_dispatch<false>(plan.radix[i], buf, rowstride, lncol, plan.n, n, twN, tid, nthr);
+    n /= plan.radix[i];
+    lds_barrier();
+  }
+}
+
+// Unnormalised inverse whose last pass hands its results to store(f, i, value) and writes no LDS.
+template <class Store>
+__device__ __forceinline__ void mixed_inverse_to(double2* buf, int rowstride, int lncol, const FftPlanDev& plan,
+                                                 const double2* twN, int tid, int nthr, Store store) {
+  int n = 1;
+  for (int i = plan.npass - 1; i >= 1; --i) {
+    n *= plan.radix[i];
+    mixed_dispatch<true>(plan.radix[i], buf, rowstride, lncol, plan.n, n, twN, tid, nthr);
+    lds_barrier();
+  }
+  mixed_dispatch_io<true>(plan.radix[0], lncol, plan.n, plan.n, twN, tid, nthr, false,
+                          [&](int f, int i) { return buf[i * rowstride + f]; }, store);
 }
 
 

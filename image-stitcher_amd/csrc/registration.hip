@@ -46,7 +46,7 @@ constexpr int kThreads = 256;
 constexpr int kMaxK = 16;       // peaks a block / a pair can report
 constexpr int kNumCand = 32;    // 2 peaks x 16 signed interpretations: the discrete search of the default path
 constexpr int kNumCandWide = 160;  // 10 peaks x 16: the candidate set of the reference's consensus stage (MISTITCH_REG_PEAKS10)
-constexpr int kNccChunks = 8;   // workgroups cooperating on one candidate
+constexpr int kNccChunks = 8;   // workgroups cooperating on one candidate (2, 4 and 16 are all slower on 2048 x 256 strips)
 // A pair has n_cand + 1 candidate slots (n_cand = kNumCand or kNumCandWide, a kernel argument): the last slot
 // holds the subpixel estimate's rounded shift (flag 1 when unused).
 constexpr int kUpsMax = 160;    // largest upsampled region side (ceil(1.5 * upsample factor))
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
   // spectrum itself (2.57 -> 2.38 ms on the 2048 x 256 strips; the pass is bound by LDS traffic).  complex64
   // columns lose by it (1.45 -> 2.37 ms: 8-byte accesses, sixteen to a radix-16 butterfly) and keep the
   // separate copy loops.
-  constexpr bool kFuseFirst = !MIXED && sizeof(T) == 8;
+  constexpr bool kFuseFirst = sizeof(T) == 8;
   constexpr bool kFuseLast = kFuseFirst;
   if constexpr (!kFuseFirst) {
     {
@@ -780,10 +780,14 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
     // the first radix pass takes the columns straight from the slabs: lanes of one row read its 2C
     // columns (two runs of 128 or 64 bytes), and nothing is written to LDS that the pass would only read back
     MS_STAMP(1, 1);
-    fft_forward_from<T, MAXR>(buf, addr, ncol, planS, tw, tid, NT, true, [&](int c, int q) {
+    auto from_slabs = [&](int c, int q) {
       const int pos = c < na ? un.a0 + c : un.b0 + (c - na);
       return Zs[(pos / kSlab) * sp + q * kSlab + pos % kSlab];
-    });
+    };
+    if constexpr (MIXED)
+      mixed_forward_from(buf, rs, lncol, planS, twN, tid, NT, true, from_slabs);
+    else
+      fft_forward_from<T, MAXR>(buf, addr, ncol, planS, tw, tid, NT, true, from_slabs);
   }
   MS_STAMP(1, 2);
   const bool partner_in_a = mp >= un.a0 && mp < un.a0 + na;
@@ -840,8 +844,11 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
     }
   } else {
     // the last radix pass stores its results itself (the na columns of a row are one run of 128 or 64 bytes)
-    fft_inverse_to<T, MAXR>(buf, addr, na, planS, tw, tid, NT,
-                            [&](int c, int q, cx<T> v) { Z[(int64_t)q * Lp + col0 + c] = v; });
+    auto to_spectrum = [&](int c, int q, cx<T> v) { Z[(int64_t)q * Lp + col0 + c] = v; };
+    if constexpr (MIXED)
+      mixed_inverse_to(buf, rs, lna, planS, twN, tid, NT, to_spectrum);
+    else
+      fft_inverse_to<T, MAXR>(buf, addr, na, planS, tw, tid, NT, to_spectrum);
     MS_STAMP(1, 4);
   }
   MS_STAMP(1, 5);
