@@ -33,7 +33,7 @@ EXPORTS = [
     "mistitch_pcm", "mistitch_pcm_topk", "mistitch_ncc", "mistitch_edge_variance",
     "mistitch_apply_flatfield", "mistitch_fuse", "mistitch_mip", "mistitch_synchronize",
     "mistitch_profile_enable", "mistitch_profile_collect", "mistitch_subpixel_shift",
-    "mistitch_set_upsample_factor", "mistitch_pyramid", "mistitch_refine_pairs",
+    "mistitch_set_upsample_factor", "mistitch_pyramid", "mistitch_chunk_layout", "mistitch_refine_pairs",
     "mistitch_register_pairs_flatfield", "mistitch_fuse_static", "mistitch_register_pairs_candidates",
 ]
 
@@ -74,6 +74,7 @@ def _load() -> C.CDLL:
         "mistitch_fuse_static": [vp, vp, i32, i32, i32, i64, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32],
         "mistitch_mip": [vp, vp, i32, i64, i64, vp],
         "mistitch_pyramid": [vp, vp, i32, i32, i32, i32, C.POINTER(vp)],
+        "mistitch_chunk_layout": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "mistitch_synchronize": [vp],
         "mistitch_profile_enable": [vp, i32],
         "mistitch_profile_collect": [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(i32), i32,

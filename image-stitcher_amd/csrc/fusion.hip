@@ -1046,6 +1046,80 @@ extern "C" int mistitch_pyramid(mistitch_ctx* ctx, const uint16_t* image, int n_
   return MISTITCH_OK;
 }
 
+// ---- chunk layout for the array writer ---------------------------------------------------------
+// One workgroup per row of one chunk: chunk (plane, cy, cx), row r inside it.  The row's chunk_w
+// elements are contiguous on both sides, so the copy moves 16-byte groups when both sides allow it
+// (row lengths and chunk widths in bytes multiples of 16, aligned bases) and single elements
+// otherwise; what sticks out of the image is written as zeros.
+template <int ES, bool VEC>
+__global__ __launch_bounds__(256) void k_chunk_layout(const unsigned char* __restrict__ image, int h, int w, int chunk_h,
+                                                      int chunk_w, int ncy, int ncx, unsigned char* __restrict__ out) {
+  const int64_t row_id = blockIdx.x;  // ((plane * ncy + cy) * ncx + cx) * chunk_h + r
+  const int r = (int)(row_id % chunk_h);
+  const int64_t chunk_id = row_id / chunk_h;
+  const int cx = (int)(chunk_id % ncx);
+  const int64_t pc = chunk_id / ncx;
+  const int cy = (int)(pc % ncy);
+  const int64_t plane = pc / ncy;
+  const int y = cy * chunk_h + r, x0 = cx * chunk_w;
+  const int valid = y < h ? min(chunk_w, w - x0) : 0;  // elements of this row that exist in the image
+  const unsigned char* src = image + ((plane * h + y) * (int64_t)w + x0) * ES;
+  unsigned char* dst = out + row_id * (int64_t)chunk_w * ES;
+  if constexpr (VEC) {
+    constexpr int kPer = 16 / ES;
+    const int groups = chunk_w / kPer, full = valid / kPer;
+    for (int g = threadIdx.x; g < groups; g += 256) {
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (g < full) {
+        v = *reinterpret_cast<const uint4*>(src + (int64_t)g * 16);
+      } else if (g * kPer < valid) {  // the group the image's edge cuts
+        unsigned char tmp[16] = {0};
+        const int nb = (valid - g * kPer) * ES;
+        for (int b = 0; b < nb; ++b) tmp[b] = src[(int64_t)g * 16 + b];
+        v = *reinterpret_cast<const uint4*>(tmp);
+      }
+      __builtin_nontemporal_store(v.x, reinterpret_cast<unsigned*>(dst + (int64_t)g * 16));
+      __builtin_nontemporal_store(v.y, reinterpret_cast<unsigned*>(dst + (int64_t)g * 16) + 1);
+      __builtin_nontemporal_store(v.z, reinterpret_cast<unsigned*>(dst + (int64_t)g * 16) + 2);
+      __builtin_nontemporal_store(v.w, reinterpret_cast<unsigned*>(dst + (int64_t)g * 16) + 3);
+    }
+  } else {
+    for (int i = threadIdx.x; i < chunk_w; i += 256) {
+      if constexpr (ES == 2) {
+        reinterpret_cast<uint16_t*>(dst)[i] = i < valid ? reinterpret_cast<const uint16_t*>(src)[i] : (uint16_t)0;
+      } else {
+        reinterpret_cast<unsigned long long*>(dst)[i] = i < valid ? reinterpret_cast<const unsigned long long*>(src)[i] : 0ull;
+      }
+    }
+  }
+}
+
+extern "C" int mistitch_chunk_layout(mistitch_ctx* ctx, const void* image, int elem_size, int n_planes, int h, int w,
+                                     int chunk_h, int chunk_w, void* out) {
+  MS_REQUIRE(ctx && image && out, MISTITCH_ERR_ARG, "NULL argument");
+  MS_REQUIRE(elem_size == 2 || elem_size == 8, MISTITCH_ERR_UNSUPPORTED, "elements of %d bytes (uint16 and float64 planes only)",
+             elem_size);
+  MS_REQUIRE(n_planes > 0 && h > 0 && w > 0 && chunk_h > 0 && chunk_w > 0, MISTITCH_ERR_ARG, "bad geometry");
+  const int ncy = (h + chunk_h - 1) / chunk_h, ncx = (w + chunk_w - 1) / chunk_w;
+  const int64_t rows = (int64_t)n_planes * ncy * ncx * chunk_h;
+  MS_REQUIRE(rows <= 0x7fffffffll, MISTITCH_ERR_UNSUPPORTED, "%lld chunk rows exceed one launch", (long long)rows);
+  MS_HIP(hipSetDevice(ctx->device));
+  const bool vec = ((int64_t)w * elem_size) % 16 == 0 && ((int64_t)chunk_w * elem_size) % 16 == 0 &&
+                   (reinterpret_cast<uintptr_t>(image) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  const unsigned char* src = reinterpret_cast<const unsigned char*>(image);
+  unsigned char* dst = reinterpret_cast<unsigned char*>(out);
+  const dim3 grid((unsigned)rows);
+  if (elem_size == 2) {
+    if (vec) MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<2, true>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, dst);
+    else MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<2, false>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, dst);
+  } else {
+    if (vec) MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<8, true>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, dst);
+    else MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<8, false>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, dst);
+  }
+  MS_HIP(hipGetLastError());
+  return MISTITCH_OK;
+}
+
 extern "C" int mistitch_mip(mistitch_ctx* ctx, const uint16_t* in, int n, int64_t pitch, int64_t n_pixels,
                             uint16_t* out) {
   MS_REQUIRE(ctx && in && out, MISTITCH_ERR_ARG, "NULL argument");

@@ -282,6 +282,18 @@ int mistitch_mip(mistitch_ctx* ctx, const uint16_t* in, int n, int64_t pitch, in
 int mistitch_pyramid(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int h, int w,
                      int n_levels, double* const* levels);
 
+/* The planes of an image, [n_planes][h][w] of uint16 (elem_size 2) or float64 (elem_size 8:
+ * the pyramid levels), laid out as the chunks a Zarr array with chunks (1, 1, 1, chunk_h,
+ * chunk_w) stores them: out[plane][cy][cx][chunk_h][chunk_w], cy < ceil(h / chunk_h),
+ * cx < ceil(w / chunk_w), every chunk whole and C-ordered, the part of an edge chunk that
+ * sticks out of the image zero (the array's fill value).  Each chunk of `out` is then the
+ * exact byte content of one uncompressed chunk file (little-endian), or the input block of
+ * its compressor.  Serves the writer of Stitcher.save_region_ome_zarr (stitcher.py:526-594;
+ * chunk shape from parameters.py:695-701), which the reference leaves to dask's
+ * `da.store` rechunking on the host.                                                */
+int mistitch_chunk_layout(mistitch_ctx* ctx, const void* image, int elem_size, int n_planes, int h, int w,
+                          int chunk_h, int chunk_w, void* out);
+
 /* Per-kernel timing with HIP events recorded on the context's stream around
  * every launch (measurement aid; no counterpart in the reference).  Enable,
  * run any entry points, then collect: kernel names come back '\n'-separated in

@@ -1,0 +1,97 @@
+"""The writer side of fusion (image-stitcher_amd/omezarr.py): chunk layout on the device against NumPy
+slicing and padding, the store read back chunk file by chunk file, and the attribute documents against
+what stitcher.py:489-523 and :596-645 put into them.  zarr, ome-zarr and dask are not importable here:
+the on-disk format is checked by this repository's own plain reader of the Zarr v2 directory layout
+(parity with those libraries' readers unpinned)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from image_stitcher_amd import omezarr
+
+
+def test_chunk_shape_and_level_count_rules():
+    assert omezarr.reference_chunks(2048, 2048) == (1, 1, 1, 2048, 2048)
+    assert omezarr.reference_chunks(3000, 20000) == (1, 1, 1, 3000, 12288)      # parameters.py:695-701
+    # parameters.py:1036-1041: max(1, ceil(log2(max(w, h) / 1024 * max_dimension)))
+    assert omezarr.default_pyramid_levels(1000, 900) == 1
+    assert omezarr.default_pyramid_levels(37071, 37070) == 6
+    assert omezarr.default_pyramid_levels(4096, 4096, max_dimension=3) == 4
+
+
+def test_attribute_documents():
+    ms = omezarr.multiscales_attrs("A1_t0", 3, 0.752, dz_um=1.5)
+    assert len(ms) == 1 and ms[0]["version"] == "0.4" and ms[0]["name"] == "A1_t0"
+    assert [a["name"] for a in ms[0]["axes"]] == ["t", "c", "z", "y", "x"]
+    assert [a.get("unit") for a in ms[0]["axes"]] == ["second", None, "micrometer", "micrometer", "micrometer"]
+    assert [d["path"] for d in ms[0]["datasets"]] == ["0", "1", "2"]
+    for level, d in enumerate(ms[0]["datasets"]):
+        (tr,) = d["coordinateTransformations"]
+        assert tr == {"type": "scale", "scale": [1, 1, 1.5, 0.752 * 2 ** level, 0.752 * 2 ** level]}
+    om = omezarr.omero_attrs("A1_t0", ["Fluorescence_488_nm_Ex", "BF_LED_matrix_full"], [0x1FFF00, 0xFFFFFF])
+    assert om["id"] == 1 and om["version"] == "0.4" and om["name"] == "A1_t0"
+    assert [c["label"] for c in om["channels"]] == ["Fluorescence_488_nm_Ex", "BF_LED_matrix_full"]
+    assert [c["color"] for c in om["channels"]] == ["1FFF00", "FFFFFF"]
+    assert om["channels"][0]["window"] == {"start": 0, "end": 65535, "min": 0, "max": 65535}
+    assert om["channels"][0]["active"] is True and om["channels"][0]["coefficient"] == 1 and om["channels"][0]["family"] == "linear"
+
+
+def _np_chunks(img, ch, cw):
+    planes, h, w = img.shape
+    ncy, ncx = -(-h // ch), -(-w // cw)
+    padded = np.zeros((planes, ncy * ch, ncx * cw), dtype=img.dtype)
+    padded[:, :h, :w] = img
+    return padded.reshape(planes, ncy, ch, ncx, cw).transpose(0, 1, 3, 2, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,chunk", [((3, 300, 520), (128, 256)),     # 16-byte groups, edge chunks on both axes
+                                          ((2, 257, 515), (100, 99)),      # nothing aligned: element path
+                                          ((1, 64, 64), (64, 64)),          # a single chunk
+                                          ((2, 130, 1000), (512, 4096)),    # chunks larger than the image
+                                          ((1, 96, 1016), (32, 248))])      # aligned rows, an edge cut inside a 16-byte group
+def test_chunk_layout_matches_numpy(shape, chunk):
+    import torch
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 65536, size=shape, dtype=np.uint16)
+    dev = torch.from_numpy(img.view(np.int16)).cuda().view(torch.uint16)
+    got = omezarr.chunk_layout(dev, *chunk).cpu().view(torch.int16).numpy().view(np.uint16)
+    assert np.array_equal(got, _np_chunks(img, *chunk))
+    f = rng.standard_normal(shape)
+    gotf = omezarr.chunk_layout(torch.from_numpy(f).cuda(), *chunk).cpu().numpy()
+    assert np.array_equal(gotf, _np_chunks(f, *chunk))
+
+
+@pytest.mark.gpu
+def test_written_store_reads_back(tmp_path):
+    import torch
+    rng = np.random.default_rng(11)
+    n_c, n_z, h, w = 2, 3, 301, 530
+    mosaic = rng.integers(0, 65536, size=(n_c, n_z, h, w), dtype=np.uint16)
+    dev = torch.from_numpy(mosaic.view(np.int16)).cuda().view(torch.uint16)
+    path = str(tmp_path / "A1_stitched.ome.zarr")
+    info = omezarr.write_ome_zarr(path, dev, ["a", "b"], [0xFF0000, 0x00FF00], px_um=0.5, tile_h=128, tile_w=256,
+                                  n_levels=3, name="A1_t0")
+    assert info["chunks"] == (1, 1, 1, 128, 256)
+    assert json.load(open(os.path.join(path, ".zgroup"))) == {"zarr_format": 2}
+    attrs = json.load(open(os.path.join(path, ".zattrs")))
+    assert attrs["multiscales"][0]["datasets"][2]["coordinateTransformations"][0]["scale"] == [1, 1, 1.0, 2.0, 2.0]
+    assert len(attrs["omero"]["channels"]) == 2
+    for level in range(3):
+        meta = json.load(open(os.path.join(path, str(level), ".zarray")))
+        assert meta["shape"] == [1, n_c, n_z, h >> level, w >> level] and meta["chunks"] == [1, 1, 1, 128, 256]
+        assert meta["dtype"] == ("<u2" if level == 0 else "<f8") and meta["compressor"] is None and meta["order"] == "C"
+        assert meta["dimension_separator"] == "/" and meta["zarr_format"] == 2
+        got = omezarr.read_level(path, level)
+        if level == 0:
+            want = mosaic[None]
+        else:   # dask.array.coarsen(np.mean, ..., trim_excess=True): float64 block means (stitcher.py:652-668)
+            s = 2 ** level
+            hh, ww = (h // s) * s, (w // s) * s
+            want = mosaic[:, :, :hh, :ww].astype(np.float64).reshape(n_c, n_z, hh // s, s, ww // s, s).mean(axis=(3, 5))[None]
+        assert got.shape == want.shape and np.array_equal(got, want)
+        # every chunk file is one whole chunk
+        f = os.path.join(path, str(level), "0", "1", "2", "0", "0")
+        assert os.path.getsize(f) == 128 * 256 * (2 if level == 0 else 8)
