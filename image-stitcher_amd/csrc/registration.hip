@@ -381,7 +381,13 @@ __global__ void k_transpose_strips(const uint16_t* tiles, int64_t tile_pitch, in
 
 // Same for strips whose sides are multiples of 64 and whose rows are 16-byte
 // aligned: 64 x 64 tiles, 16 bytes per lane in and out.
-// grid (L / 64, S / 64, 2 * pairs_in_pass), block 256.
+// EDGE: the short side (the edge width) is arbitrary: the strip of the first tile then starts at an unaligned
+// column (16-byte loads at 2-byte alignment), and the last 64 x 64 tile is cut by the strip's edge.
+// grid (L / 64, ceil(S / 64), 2 * pairs_in_pass), block 256.
+struct __attribute__((packed, aligned(2))) StripGroup {
+  unsigned d[4];
+};
+template <bool EDGE>
 __global__ __launch_bounds__(256) void k_transpose_strips64(const uint16_t* tiles, int64_t tile_pitch, int H, int W,
                                                             int w_left, const int32_t* pair_idx, const PairDesc* desc,
                                                             const int8_t* status, int pair0) {
@@ -396,8 +402,23 @@ __global__ __launch_bounds__(256) void k_transpose_strips64(const uint16_t* tile
   const int t = threadIdx.x, sub = t & 7, row = t >> 3;  // 8 lanes cover one 128-byte row segment
   uint4 v[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-    v[i] = *reinterpret_cast<const uint4*>(src + (int64_t)(l0 + row + 32 * i) * W + s0 + 8 * sub);
+  for (int i = 0; i < 2; ++i) {
+    const uint16_t* at = src + (int64_t)(l0 + row + 32 * i) * W + s0 + 8 * sub;
+    if constexpr (EDGE) {
+      const int left = w_left - (s0 + 8 * sub);  // columns of this group inside the strip
+      if (left >= 8) {
+        const StripGroup g = *reinterpret_cast<const StripGroup*>(at);
+        v[i] = make_uint4(g.d[0], g.d[1], g.d[2], g.d[3]);
+      } else {  // the group the strip's edge cuts (or one beyond it): nothing is read outside the strip
+        unsigned px[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) px[q] = q < left ? at[q] : 0u;
+        v[i] = make_uint4(px[0] | (px[1] << 16), px[2] | (px[3] << 16), px[4] | (px[5] << 16), px[6] | (px[7] << 16));
+      }
+    } else {
+      v[i] = *reinterpret_cast<const uint4*>(at);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const unsigned w4[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
@@ -418,7 +439,7 @@ __global__ __launch_bounds__(256) void k_transpose_strips64(const uint16_t* tile
     o.y = w4[1];
     o.z = w4[2];
     o.w = w4[3];
-    *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + s) * H + l0 + 8 * sub) = o;
+    if (!EDGE || s0 + s < w_left) *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + s) * H + l0 + 8 * sub) = o;
   }
 }
 
@@ -3418,7 +3439,10 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
       }
       MS_LAUNCH(ctx, "k_edge_stats", k_edge_stats_staged, dim3(2, n), dim3(kThreads), 0, ws.desc, status, pair0, 2e3);
     } else if (vec_top && H % 64 == 0 && w_left % 64 == 0) {
-      MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips64, dim3(H / 64, w_left / 64, 2 * n), dim3(256), 0, tiles,
+      MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips64<false>, dim3(H / 64, w_left / 64, 2 * n), dim3(256), 0, tiles,
+                tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
+    } else if (vec_top && H % 64 == 0) {
+      MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips64<true>, dim3(H / 64, (w_left + 63) / 64, 2 * n), dim3(256), 0, tiles,
                 tile_pitch, H, W, w_left, pair_idx, ws.desc, status, pair0);
     } else {
       MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips, dim3((H + 31) / 32, (w_left + 31) / 32, 2 * n), dim3(32, 8), 0,
@@ -3617,7 +3641,7 @@ extern "C" int mistitch_refine_pairs(mistitch_ctx* ctx, const uint16_t* tiles, i
   for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {
     const int n = std::min(chunk, n_pairs - pair0);
     if (vec_top && H % 64 == 0 && w_left % 64 == 0)
-      MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips64, dim3(H / 64, w_left / 64, 2 * n), dim3(256), 0, tiles,
+      MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips64<false>, dim3(H / 64, w_left / 64, 2 * n), dim3(256), 0, tiles,
                 tile_pitch, H, W, w_left, pair_idx, desc, status, pair0);
     else
       MS_LAUNCH(ctx, "k_transpose_strips", k_transpose_strips, dim3((H + 31) / 32, (w_left + 31) / 32, 2 * n), dim3(32, 8), 0,

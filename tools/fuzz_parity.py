@@ -131,6 +131,72 @@ def fuzz_registration_big(rng, reg, oreg, synth):
     return good, dict(kind="registration_big", grid=(rows, cols), tile=(th, tw), edge=edge, fft=fft), (out, st, exp, exp_st)
 
 
+def fuzz_mixed_radix(rng, reg, oreg, synth):
+    """Strips with a power-of-two long side and a short side that is not one: widths whose prime factors are at
+    most 13 (mixed-radix column passes, odd and even) and widths with a larger prime factor (chirp-z columns)."""
+    rows, cols = (1, 2) if rng.random() < 0.5 else (2, 1)
+    side = int(rng.choice([128, 256, 512, 1024]))
+    smooth = [3, 5, 6, 7, 9, 10, 11, 12, 13, 14, 15, 18, 20, 21, 22, 24, 25, 26, 27, 28, 30, 33, 35, 36, 39, 40, 42, 44, 45,
+              48, 49, 50, 52, 55, 56, 60, 63, 65, 66, 70, 72, 75, 77, 78, 80, 84, 88, 90, 91, 96, 98, 99, 100, 104, 105, 108,
+              110, 112, 117, 120, 121, 125, 126, 130, 132, 135, 140, 143, 144, 147, 150, 154, 156, 160, 165, 168, 169, 175,
+              176, 180, 182, 189, 192, 195, 196, 198, 200, 208, 210, 216, 220, 224, 225, 231, 234, 240, 242, 243, 245, 250, 252]
+    rough = [17, 19, 23, 29, 31, 34, 37, 38, 41, 43, 46, 47, 51, 53, 57, 58, 59, 61, 62, 67, 68, 69, 71, 73, 74, 76, 79, 82, 83,
+             85, 86, 87, 89, 92, 93, 94, 95, 97, 101, 102, 103, 106, 107, 109, 113, 127, 131, 137, 139, 149, 151, 157, 163, 167,
+             173, 179, 181, 187, 191, 193, 197, 199, 211, 221, 223, 227, 229, 233, 239, 241, 247, 251]
+    edge = int(rng.choice(smooth if rng.random() < 0.8 else rough))
+    edge = min(edge, side - 1)
+    g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, side, side, overlap=float(rng.uniform(0.08, 0.25)),
+                        jitter=int(rng.integers(0, 6)))
+    sub = rng.random() < 0.15
+    out, st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, subpixel=sub)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    if sub:
+        from oracle import subpixel as osp
+        exp, exp_st, _ = osp.register_pairs_subpixel(g.tiles, g.pair_idx, g.pair_dir, edge)
+        ok = exp_st == 0
+        good = bool(np.array_equal(st != 0, exp_st != 0) and (not ok.any() or np.abs(out[ok, 1:] - exp[ok, 1:]).max() <= 0.01 + 1e-9
+                                                                or (exp[ok, 0] <= 0.5).all()))
+    else:
+        exp, exp_st = oreg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, polish=False)
+        good = bool(np.array_equal(st, exp_st) and np.array_equal(out[:, 1:], exp[:, 1:])
+                    and np.allclose(out[:, 0], exp[:, 0], rtol=0, atol=1e-9, equal_nan=True))
+    return good, dict(kind="mixed_radix", grid=(rows, cols), tile=side, edge=edge, sub=sub), (out, st, exp, exp_st)
+
+
+def fuzz_peaks10(rng, reg, oreg, synth):
+    """The ten-peak candidate search (MISTITCH_REG_PEAKS10) against the oracle's statement of the reference's
+    generate_translation_candidates + best-NCC fallback, winner and whole candidate table."""
+    rows, cols = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    if rows * cols == 1:
+        cols = 2
+    th, tw = (int(rng.choice([64, 128, 256, int(rng.integers(40, 200))])) for _ in range(2))
+    edge = int(rng.choice([16, 32, 64, int(rng.integers(6, 60))]))
+    g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, th, tw, overlap=float(rng.uniform(0.1, 0.3)),
+                        jitter=int(rng.integers(0, 4)))
+    out, st, table = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, peaks10=True, return_candidates=True)
+    out, st, table = out.cpu().numpy(), st.cpu().numpy(), table.cpu().numpy()
+    exp, exp_st, tables = oreg.register_pairs_peaks10(g.tiles, g.pair_idx, g.pair_dir, edge)
+    good = bool(np.array_equal(st != 0, exp_st != 0))
+    ok = exp_st == 0
+    good = good and np.array_equal(out[ok, 1:], exp[ok, 1:]) and np.allclose(out[ok, 0], exp[ok, 0], rtol=0, atol=1e-9)
+    return bool(good), dict(kind="peaks10", grid=(rows, cols), tile=(th, tw), edge=edge), (out, st, exp, exp_st)
+
+
+def fuzz_window(rng, reg, oreg, synth):
+    """The Hann window option against the oracle's NumPy statement of it."""
+    rows, cols = (1, 2) if rng.random() < 0.5 else (2, 1)
+    th, tw = (int(rng.choice([64, 128, 256, int(rng.integers(40, 260))])) for _ in range(2))
+    edge = int(rng.choice([16, 32, 64, int(rng.integers(6, 60))]))
+    g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, th, tw, overlap=float(rng.uniform(0.1, 0.3)),
+                        jitter=int(rng.integers(0, 4)))
+    out, st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, window="hann")
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    exp, exp_st = oreg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, polish=False, window="hann")
+    good = bool(np.array_equal(st, exp_st) and np.array_equal(out[:, 1:], exp[:, 1:])
+                and np.allclose(out[:, 0], exp[:, 0], rtol=0, atol=1e-9, equal_nan=True))
+    return good, dict(kind="window", grid=(rows, cols), tile=(th, tw), edge=edge), (out, st, exp, exp_st)
+
+
 def fuzz_apis(rng, reg, fu, oreg, ofu, synth):
     """The one-call mirrors: ncc, pcm_topk, flatfield, z projection, pyramid."""
     which = int(rng.integers(5))
@@ -396,7 +462,10 @@ def main():
                "fusion_tiny": lambda: fuzz_fusion_tiny(rng, fu, ofu, synth),
                "featureless": lambda: fuzz_featureless(rng, reg, oreg, synth),
                "registration_wild": lambda: fuzz_registration_wild(rng, reg, oreg, synth),
-               "fusion_ff_extreme": lambda: fuzz_fusion_ff_extreme(rng, fu, ofu, synth)}
+               "fusion_ff_extreme": lambda: fuzz_fusion_ff_extreme(rng, fu, ofu, synth),
+               "mixed_radix": lambda: fuzz_mixed_radix(rng, reg, oreg, synth),
+               "peaks10": lambda: fuzz_peaks10(rng, reg, oreg, synth),
+               "window": lambda: fuzz_window(rng, reg, oreg, synth)}
     kinds = [k for k in runners if not args.only or k in args.only.split(",")]
     counts = {k: 0 for k in kinds}
     last = t0
@@ -406,7 +475,7 @@ def main():
         counts[kind] += 1
         if not good:
             print("DISAGREEMENT", desc, flush=True)
-            if kind in ("registration", "subpixel", "refine", "registration_big", "registration_tiny", "featureless", "registration_wild") or desc.get("api") in ("ncc", "pcm_topk"):
+            if kind in ("registration", "subpixel", "refine", "registration_big", "registration_tiny", "featureless", "registration_wild", "mixed_radix", "peaks10", "window") or desc.get("api") in ("ncc", "pcm_topk"):
                 out, st, exp, exp_st = data
                 print(np.concatenate([out, st[:, None], exp, exp_st[:, None]], axis=1))
             else:
