@@ -144,38 +144,59 @@ __device__ __forceinline__ void fetch_window(const uint16_t* src, const void* ff
 // writes whole cache lines, kGX KiB of one row at a time.  A block's pixel columns lie in
 // [bx * BW - 7, bx * BW + BW) with BW = 512 * GX.
 
-// One wave per output block lists, in placement order, the tiles that touch it:
+// One wave lists, in placement order, the tiles that touch each of kBinRows vertically adjacent output blocks
+// (every tile's position is loaded once per wave, not once per block):
 // bins[block][0] = how many (may exceed kMaxCand: the fuse kernel then scans every
 // tile), bins[block][1..] = the first kMaxCand tile indices.
-// grid = ceil(n_blocks / 4) workgroups of 4 waves; blocks are numbered as k_fuse's grid.
+// grid = ceil(n_groups / 4) workgroups of 4 waves, n_groups = gx * ceil(gy / kBinRows) * n_planes; blocks are
+// numbered as k_fuse's grid.
+constexpr int kBinRows = 8;
 __global__ __launch_bounds__(256) void k_fuse_bins(int n_tiles, int H, int W, const int32_t* __restrict__ tile_yx,
                                                    const int32_t* __restrict__ tile_plane, int32_t* __restrict__ bins,
                                                    int gx, int gy, int n_planes, int Wm, int row0, int row1, int kBW,
                                                    int32_t* ff_verdict) {
   const int lane = threadIdx.x & 63;
   if (blockIdx.x == 0 && threadIdx.x == 0) *ff_verdict = 1;  // k_ff_check, next on the stream, may clear it
-  const int64_t blk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (blk >= (int64_t)gx * gy * n_planes) return;
-  const int bx = (int)(blk % gx), by = (int)((blk / gx) % gy), plane = (int)(blk / ((int64_t)gx * gy));
+  const int gyg = (gy + kBinRows - 1) / kBinRows;
+  const int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (grp >= (int64_t)gx * gyg * n_planes) return;
+  const int bx = (int)(grp % gx), byg = (int)((grp / gx) % gyg), plane = (int)(grp / ((int64_t)gx * gyg));
   const int x0 = max(bx * kBW - 7, 0), x1 = min(bx * kBW + kBW, Wm);
-  const int y0 = row0 + by * kBH, y1 = min(y0 + kBH, row1);
-  int32_t* bin = bins + blk * (kMaxCand + 1);
-  int count = 0;
+  const int by0 = byg * kBinRows, nby = min(kBinRows, gy - by0);
+  const int ya = row0 + by0 * kBH, yb = min(ya + nby * kBH, row1);  // rows of the whole group
+  int count[kBinRows];
+#pragma unroll
+  for (int k = 0; k < kBinRows; ++k) count[k] = 0;
   for (int base = 0; base < n_tiles; base += 64) {
     const int t = base + lane;
-    bool hit = false;
+    int ty = 0, tx = 0;
+    bool near = false;
     if (t < n_tiles && tile_plane[t] == plane) {
-      const int ty = tile_yx[2 * t], tx = tile_yx[2 * t + 1];
-      hit = ty < y1 && ty + H > y0 && tx < x1 && tx + W > x0;
+      ty = tile_yx[2 * t];
+      tx = tile_yx[2 * t + 1];
+      near = ty < yb && ty + H > ya && tx < x1 && tx + W > x0;
     }
-    const unsigned long long mask = __ballot(hit);
-    if (hit) {
-      const int slot = count + __popcll(mask & ((1ull << lane) - 1ull));
-      if (slot < kMaxCand) bin[1 + slot] = t;
+    if (__ballot(near) == 0ull) continue;  // wave-uniform
+#pragma unroll
+    for (int k = 0; k < kBinRows; ++k) {
+      if (k < nby) {
+        const int y0 = ya + k * kBH, y1 = min(y0 + kBH, row1);
+        const bool hit = near && ty < y1 && ty + H > y0;
+        const unsigned long long mask = __ballot(hit);
+        if (hit) {
+          const int slot = count[k] + __popcll(mask & ((1ull << lane) - 1ull));
+          if (slot < kMaxCand) bins[(((int64_t)plane * gy + by0 + k) * gx + bx) * (kMaxCand + 1) + 1 + slot] = t;
+        }
+        count[k] += __popcll(mask);
+      }
     }
-    count += __popcll(mask);
   }
-  if (lane == 0) bin[0] = count;
+  if (lane < nby) {
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kBinRows; ++k) c = lane == k ? count[k] : c;
+    bins[(((int64_t)plane * gy + by0 + lane) * gx + bx) * (kMaxCand + 1)] = c;
+  }
 }
 
 __device__ __forceinline__ void store_window(uint16_t* dst, const uint16_t (&px)[8], unsigned valid) {
@@ -944,7 +965,8 @@ static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int 
   // flatfield verdict before anything reads them
   const int32_t* bins = reinterpret_cast<const int32_t*>(ws);
   int32_t* ff_safe = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(ws) + bins_bytes);
-  MS_LAUNCH(ctx, "k_fuse_bins", k_fuse_bins, dim3((unsigned)((n_blocks + 3) / 4)), dim3(256), 0, n_tiles, tile_h, tile_w,
+  const int64_t n_bin_groups = (int64_t)grid.x * ((grid.y + kBinRows - 1) / kBinRows) * grid.z;
+  MS_LAUNCH(ctx, "k_fuse_bins", k_fuse_bins, dim3((unsigned)((n_bin_groups + 3) / 4)), dim3(256), 0, n_tiles, tile_h, tile_w,
             tile_yx, tile_plane, reinterpret_cast<int32_t*>(ws), (int)grid.x, (int)grid.y, n_planes, mosaic_w,
             row0, row1, 512 * GX, ff_safe);
   if (ff_type == MISTITCH_FF_F32 && n_tiles > 0)
