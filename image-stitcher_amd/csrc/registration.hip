@@ -887,7 +887,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
                                                            int abs_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
-  __shared__ Peak red[kThreads / 64];
+  __shared__ Peak red[2 * kThreads / 64];
   const int p = pair0 + blockIdx.y;
   // the pair's status and descriptor are looked up here but tested only once the spectrum loads are on their
   // way (the workspace rows exist whatever the pair's state): one memory round trip in front of the transform
@@ -1019,13 +1019,32 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       if (tid == 0) partial_abs[(int64_t)blockIdx.y * abs_stride + blockIdx.x] = best;
       __syncthreads();
     }
-    for (int round = 0; round < k; ++round) {
-      const Peak best = block_argmax(b1, red);
-      if (tid == 0) partial[(int64_t)blockIdx.y * partial_stride + blockIdx.x * k + round] = best;
-      if (best.loc >= 0 && best.loc == b1.loc) {
-        b1 = b2;
-        b2 = Peak{-INFINITY, -1, -1};
+    // every wave's two best (the lane whose best was the wave's first offers its second), then one
+    // barrier and a merge of the 2 x 4 entries by one thread: one barrier instead of two per round
+    const Peak none{-INFINITY, -1, -1};
+    const Peak w1 = wave_best_peak(b1, peak_better);
+    if (w1.loc >= 0 && w1.loc == b1.loc) b1 = b2;
+    const Peak w2 = k > 1 ? wave_best_peak(b1, peak_better) : none;
+    if ((tid & 63) == 0) {
+      red[2 * (tid >> 6)] = w1;
+      red[2 * (tid >> 6) + 1] = w2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      Peak t1 = none, t2 = none;
+#pragma unroll
+      for (int e = 0; e < 2 * kThreads / 64; ++e) {
+        const Peak o = red[e];
+        if (peak_better(o.val, o.key, t1.val, t1.key)) {
+          t2 = t1;
+          t1 = o;
+        } else if (peak_better(o.val, o.key, t2.val, t2.key)) {
+          t2 = o;
+        }
       }
+      Peak* dst = partial + (int64_t)blockIdx.y * partial_stride + blockIdx.x * k;
+      dst[0] = t1;
+      if (k > 1) dst[1] = t2;
     }
     MS_STAMP(2, 3);
     return;
