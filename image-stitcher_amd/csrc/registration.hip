@@ -884,7 +884,11 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
                                                            const uint16_t* __restrict__ mirror_fill, int n_stored,
                                                            int NF, const cx<T>* spectrum, int k, Peak* partial,
                                                            int partial_stride, double* pcm_out, Peak* partial_abs,
-                                                           int abs_stride) {
+                                                           int abs_stride, int nblk, int seq) {
+  // nblk: blocks of 2 NF lines a strip has (= entries of a pair's partial lists); seq: how many of them, one after
+  // the other, this workgroup transforms (more than one only where the values are ranked in the last radix pass:
+  // the per-lane ranking then runs across all of them and the workgroup reduces once; its other list entries are
+  // written empty).  grid (ceil(nblk / seq), pairs_in_pass).
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
   __shared__ Peak red[2 * kThreads / 64];
@@ -896,12 +900,14 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
   const int tid = threadIdx.x;
   LineAddr<T> addr{LineAddr<T>::padded(L) + 1};
   const Twiddles<T> tw = load_twiddles<T>(buf + NF * addr.fstride, planL, tid, kThreads);
-  const int s0 = blockIdx.x * NF * 2;
+  const int blk0 = blockIdx.x * seq;
+  int s0 = blk0 * NF * 2;
   const int lL = 31 - __builtin_clz(L);  // a power of two on this path
   const int Lp = spectrum_pitch<T>(n_stored);
   const cx<T>* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
   MS_STAMP(2, 0);
-  {
+  // lines s0 .. s0 + 2 NF into LDS; false (for every lane alike) when the pair is not this launch's to transform
+  auto load_lines = [&]() -> bool {
     // Only the stored half of every line is read; the other half is its conjugate
     // mirror and is written to LDS by the lane that loaded the stored value.
     constexpr int U = 8;  // two loads per element: 16 in flight per lane
@@ -920,7 +926,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
         at_mir[u] = mirror_fill[i];
       }
       if (pair_status != MISTITCH_PAIR_OK || d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed))
-        return;  // the same for every lane of the workgroup
+        return false;  // the same for every lane of the workgroup
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         MS_PIN(g1[u].x); MS_PIN(g1[u].y);
@@ -939,7 +945,9 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
         }
       }
     }
-  }
+    return true;
+  };
+  if (!load_lines()) return;
   __syncthreads();
   MS_STAMP(2, 1);
   // The production case (two peaks, no PCM plane wanted) ranks the values as the last radix pass produces
@@ -1005,7 +1013,14 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
       }
     };
     if (rank_in_last_pass) {
-      fft_inverse_to<T, kLongMaxRadix<T>>(buf, addr, NF, planL, tw, tid, kThreads, take);
+      for (int it = 0;;) {
+        fft_inverse_to<T, kLongMaxRadix<T>>(buf, addr, NF, planL, tw, tid, kThreads, take);
+        s0 += NF * 2;
+        if (++it >= seq || s0 >= S) break;  // the same for every lane
+        __syncthreads();                    // the last pass has read the lines that the next ones replace
+        load_lines();
+        __syncthreads();
+      }
     } else {
       for (int e = tid; e < NF * L; e += kThreads) {
         const int f = e >> lL, l = e & (L - 1);
@@ -1014,14 +1029,15 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
     }
     ba.loc = ba.key >= 0 ? 0 : -1;
     Peak b1{k1 >= 0 ? (double)v1 * out_scale : -INFINITY, k1, k1}, b2{k2 >= 0 ? (double)v2 * out_scale : -INFINITY, k2, k2};
+    const Peak none{-INFINITY, -1, -1};
     if (partial_abs != nullptr) {
       const Peak best = block_argmax_first(ba, red);
-      if (tid == 0) partial_abs[(int64_t)blockIdx.y * abs_stride + blockIdx.x] = best;
+      if (tid == 0) partial_abs[(int64_t)blockIdx.y * abs_stride + blk0] = best;
+      if (tid > 0 && tid < seq && blk0 + tid < nblk) partial_abs[(int64_t)blockIdx.y * abs_stride + blk0 + tid] = none;
       __syncthreads();
     }
     // every wave's two best (the lane whose best was the wave's first offers its second), then one
     // barrier and a merge of the 2 x 4 entries by one thread: one barrier instead of two per round
-    const Peak none{-INFINITY, -1, -1};
     const Peak w1 = wave_best_peak(b1, peak_better);
     if (w1.loc >= 0 && w1.loc == b1.loc) b1 = b2;
     const Peak w2 = k > 1 ? wave_best_peak(b1, peak_better) : none;
@@ -1042,9 +1058,13 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
           t2 = o;
         }
       }
-      Peak* dst = partial + (int64_t)blockIdx.y * partial_stride + blockIdx.x * k;
+      Peak* dst = partial + (int64_t)blockIdx.y * partial_stride + blk0 * k;
       dst[0] = t1;
       if (k > 1) dst[1] = t2;
+    } else if (tid < seq && blk0 + tid < nblk) {  // the list entries of the other blocks this workgroup covered
+      Peak* dst = partial + (int64_t)blockIdx.y * partial_stride + (blk0 + tid) * k;
+      dst[0] = none;
+      if (k > 1) dst[1] = none;
     }
     MS_STAMP(2, 3);
     return;
@@ -1143,6 +1163,10 @@ __device__ __forceinline__ void bluestein_lines(double2* buf, const LineAddr<dou
 // The same with the chirp and filter values a lane needs held in registers (lane tid of an NT-wide
 // workgroup only ever touches elements tid + NT j of a line) and no division in the element loops:
 // for n <= kThreads * kBlueC and M <= kThreads * kBlueH.
+#ifndef MS_LONG_INV_SEQ
+#define MS_LONG_INV_SEQ 2
+#endif
+constexpr int kLongInvSeq = MS_LONG_INV_SEQ;  // blocks of lines one workgroup of the last pass may take in turn
 constexpr int kMixedShortThreads = 256;  // radix-13 butterflies: 15 a column of 195, 240 for 16 columns
 constexpr int kGenShortThreads = 512, kGenShortRadix = 8;  // as the power-of-two column pass: more waves, radix-8 plans
 constexpr int kBlueC = 2, kBlueH = 4;
@@ -3225,10 +3249,16 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
               ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
   }
   if ((rc = allow_lds(ctx, k_fft_long_inv<T>, cfg.lds_inv))) return rc;
-  MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv<T>), dim3((cfg.S + 2 * cfg.NF_inv - 1) / (2 * cfg.NF_inv), n), dim3(kThreads), cfg.lds_inv, ws.desc,
-                     status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored,
-            cfg.NF_inv, spec, k, ws.partial,
-                     ws.partial_stride, pcm_out, ws.n_up ? ws.partial_abs : (Peak*)nullptr, ws.abs_stride);
+  // Where the last radix pass ranks its values (two peaks, no PCM plane), a workgroup takes several blocks of lines
+  // in turn and reduces once - as long as the launch still fills the chip a few times over.
+  const int nblk_inv = (cfg.S + 2 * cfg.NF_inv - 1) / (2 * cfg.NF_inv);
+  int seq = 1;
+  if (k > 0 && k <= 2 && pcm_out == nullptr)
+    while (seq < kLongInvSeq && (int64_t)((nblk_inv + 2 * seq - 1) / (2 * seq)) * n >= 2048) seq *= 2;
+  MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv<T>), dim3((nblk_inv + seq - 1) / seq, n), dim3(kThreads), cfg.lds_inv, ws.desc,
+            status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored, cfg.NF_inv,
+            spec, k, ws.partial, ws.partial_stride, pcm_out, ws.n_up ? ws.partial_abs : (Peak*)nullptr, ws.abs_stride,
+            nblk_inv, seq);
   if (ws.n_up) {
     // subpixel refinement of these pairs, while their normalised spectra still sit in the slab buffer
     UpsTables tabs{cfg.ups_slabs, cfg.n_ups_slabs, cfg.pos2stored, cfg.stored2kappa, cfg.kappa};
