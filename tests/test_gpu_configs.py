@@ -2,6 +2,8 @@
 
   c2  10 x 10 grid of 2048^2 tiles, one channel, registration + linear (feather) blend
   c3  20 x 20 grid, 4 channels + flatfield: 760 pairs through the fused flatfield call
+  c4  96-well plate, 5 x 5 fields of view per well: 3840 pairs in one call, every well one plane of one
+      fuse call, wells sharded over 8 ranks (no halo, no exchange), one well written as OME-Zarr
   c5  50 x 50 grid, 5 z levels of one channel: 4900 pairs on the MIDDLE level, and the
       92 k x 92 k mosaic through ``stitch_region(selected_z=...)``
 
@@ -158,6 +160,75 @@ def test_c3_four_channels_with_flatfield(dev):
             got = mosaic[c, y + lo:y + hi, x + lo:x + hi].cpu().numpy()
             assert np.array_equal(got, want), (mode, c)
         del mosaic
+
+
+def test_c4_plate_of_wells_sharded_by_well(dev, tmp_path):
+    """Config 4: 96 wells x 5 x 5 fields of view of 2048^2 pixels (one channel).  Wells are independent regions
+    (tile_registration.py:2696-2875 loops them; each gets its own mosaic, stitcher.py:791-798): all 3840 pairs
+    go through one registration call, every well is solved on its own and fused as one plane of a single fuse
+    call, a rank of an 8-way split registers and fuses its 12 wells with the same rows and pixels, and a well
+    leaves as an OME-Zarr store that reads back as its mosaic."""
+    import torch
+    from image_stitcher_amd import dist, fusion, omezarr, registration
+    wells, rows, cols = 96, 5, 5
+    per_well, pairs_per_well = rows * cols, 2 * rows * cols - rows - cols
+    tiles = torch.empty((wells * per_well, TILE, TILE), dtype=torch.int16, device=dev).view(torch.uint16)
+    true, scenes_kept = [], {}
+    for w in range(wells):
+        t, true_yx, pair_idx, pair_dir, scenes = synth.make_device_acquisition(rows, cols, TILE, 1, 400 + w, dev, keep_scenes=True)
+        tiles[w * per_well:(w + 1) * per_well] = t[0]
+        true.append(true_yx)
+        if w in (0, 41, 95):
+            scenes_kept[w] = scenes[0]
+        del t, scenes
+    all_pairs = np.concatenate([pair_idx + w * per_well for w in range(wells)]).astype(np.int32)
+    all_dirs = np.tile(pair_dir, wells)
+    out, status = registration.register_pairs(tiles, all_pairs, all_dirs, EDGE)
+    out_np, st_np = out.cpu().numpy(), status.cpu().numpy()
+    assert len(all_pairs) == 3840 and (st_np == 0).all()
+    yx_all = np.empty((wells * per_well, 2), dtype=np.int32)
+    dims = []
+    for w in range(wells):
+        sl = slice(w * pairs_per_well, (w + 1) * pairs_per_well)
+        assert np.array_equal(out_np[sl, 1:].astype(np.int64), true[w][pair_idx[:, 1]] - true[w][pair_idx[:, 0]]), w
+        yx = _solve(rows, cols, pair_idx, pair_dir, out_np[sl], st_np[sl])
+        assert np.array_equal(yx, true[w] - true[w].min(axis=0)), w
+        yx_all[w * per_well:(w + 1) * per_well] = yx
+        dims.append((int(yx[:, 0].max()) + TILE, int(yx[:, 1].max()) + TILE))
+    mh, mw = max(d[0] for d in dims), max(d[1] for d in dims)      # planes sized for the largest well
+    plane = np.repeat(np.arange(wells), per_well).astype(np.int32)
+    mosaic = fusion.fuse_tiles(tiles, yx_all, plane, wells, mh, mw, mode="overwrite")
+    for w, scene in scenes_kept.items():
+        origin = true[w].min(axis=0)
+        h, wd = dims[w]
+        want = scene[origin[0]:origin[0] + h, origin[1]:origin[1] + wd].view(torch.int16)
+        covered = _covered_mask(yx_all[w * per_well:(w + 1) * per_well], h, wd, dev)
+        m = mosaic[w, :h, :wd].view(torch.int16)
+        assert int(((m != want) & covered).sum().item()) == 0, w
+        assert int(((m != 0) & ~covered).sum().item()) == 0, w
+        assert int((mosaic[w, h:] != 0).sum().item()) == 0 and int((mosaic[w, :, wd:] != 0).sum().item()) == 0, w
+    # wells over 8 ranks: contiguous runs of whole wells, nothing shared between ranks
+    covered_wells = []
+    for rank in (0, 5, 7):
+        lo, hi = dist.band_bounds(wells, 8, rank)
+        covered_wells.append((lo, hi))
+        mine = tiles[lo * per_well:hi * per_well]
+        pairs = np.concatenate([pair_idx + (w - lo) * per_well for w in range(lo, hi)]).astype(np.int32)
+        o, s = registration.register_pairs(mine, pairs, np.tile(pair_dir, hi - lo), EDGE)
+        assert torch.equal(o, out[lo * pairs_per_well:hi * pairs_per_well]) and torch.equal(s, status[lo * pairs_per_well:hi * pairs_per_well])
+        part = fusion.fuse_tiles(mine, yx_all[lo * per_well:hi * per_well], plane[lo * per_well:hi * per_well] - lo, hi - lo,
+                                 mh, mw, mode="overwrite")
+        assert torch.equal(part, mosaic[lo:hi])
+        del part
+    assert covered_wells == [(0, 12), (60, 72), (84, 96)]
+    # one well out as OME-Zarr (the reference writes one store per region, stitcher.py:465-650)
+    h, wd = dims[41]
+    store = str(tmp_path / "D6_stitched.ome.zarr")
+    info = omezarr.write_ome_zarr(store, mosaic[41, :h, :wd].contiguous().reshape(1, 1, h, wd), ["Fluorescence_488_nm_Ex"],
+                                  [0x1FFF00], px_um=0.752, tile_h=TILE, tile_w=TILE, n_levels=1, name="D6_t0")
+    assert info["chunks"] == (1, 1, 1, TILE, TILE) and info["levels"] == [(1, 1, 1, h, wd)]
+    back = omezarr.read_level(store, 0)
+    assert np.array_equal(back[0, 0, 0], mosaic[41, :h, :wd].cpu().view(torch.int16).numpy().view(np.uint16))
 
 
 def test_c5_middle_z_whole_slide(dev):
