@@ -1071,8 +1071,15 @@ extern "C" int mistitch_pyramid(mistitch_ctx* ctx, const uint16_t* image, int n_
 // ---- chunk layout for the array writer ---------------------------------------------------------
 // One workgroup per row of one chunk: chunk (plane, cy, cx), row r inside it.  The row's chunk_w
 // elements are contiguous on both sides, so the copy moves 16-byte groups when both sides allow it
-// (row lengths and chunk widths in bytes multiples of 16, aligned bases) and single elements
+// (chunk widths in bytes multiples of 16 and an aligned output: the source rows may start anywhere, as the
+// rows of a mosaic of odd width do, and are read with 16-byte loads at element alignment) and single elements
 // otherwise; what sticks out of the image is written as zeros.
+struct __attribute__((packed, aligned(2))) ChunkGroup2 {
+  unsigned d[4];
+};
+struct __attribute__((packed, aligned(8))) ChunkGroup8 {
+  unsigned d[4];
+};
 template <int ES, bool VEC>
 __global__ __launch_bounds__(256) void k_chunk_layout(const unsigned char* __restrict__ image, int h, int w, int chunk_h,
                                                       int chunk_w, int ncy, int ncx, unsigned char* __restrict__ out) {
@@ -1093,7 +1100,13 @@ __global__ __launch_bounds__(256) void k_chunk_layout(const unsigned char* __res
     for (int g = threadIdx.x; g < groups; g += 256) {
       uint4 v = make_uint4(0u, 0u, 0u, 0u);
       if (g < full) {
-        v = *reinterpret_cast<const uint4*>(src + (int64_t)g * 16);
+        if constexpr (ES == 2) {
+          const ChunkGroup2 q = *reinterpret_cast<const ChunkGroup2*>(src + (int64_t)g * 16);
+          v = make_uint4(q.d[0], q.d[1], q.d[2], q.d[3]);
+        } else {
+          const ChunkGroup8 q = *reinterpret_cast<const ChunkGroup8*>(src + (int64_t)g * 16);
+          v = make_uint4(q.d[0], q.d[1], q.d[2], q.d[3]);
+        }
       } else if (g * kPer < valid) {  // the group the image's edge cuts
         unsigned char tmp[16] = {0};
         const int nb = (valid - g * kPer) * ES;
@@ -1126,8 +1139,8 @@ extern "C" int mistitch_chunk_layout(mistitch_ctx* ctx, const void* image, int e
   const int64_t rows = (int64_t)n_planes * ncy * ncx * chunk_h;
   MS_REQUIRE(rows <= 0x7fffffffll, MISTITCH_ERR_UNSUPPORTED, "%lld chunk rows exceed one launch", (long long)rows);
   MS_HIP(hipSetDevice(ctx->device));
-  const bool vec = ((int64_t)w * elem_size) % 16 == 0 && ((int64_t)chunk_w * elem_size) % 16 == 0 &&
-                   (reinterpret_cast<uintptr_t>(image) & 15u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  const bool vec = ((int64_t)chunk_w * elem_size) % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 &&
+                   (reinterpret_cast<uintptr_t>(image) % (uintptr_t)elem_size) == 0;
   const unsigned char* src = reinterpret_cast<const unsigned char*>(image);
   unsigned char* dst = reinterpret_cast<unsigned char*>(out);
   const dim3 grid((unsigned)rows);

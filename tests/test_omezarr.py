@@ -51,7 +51,9 @@ def _np_chunks(img, ch, cw):
                                           ((2, 257, 515), (100, 99)),      # nothing aligned: element path
                                           ((1, 64, 64), (64, 64)),          # a single chunk
                                           ((2, 130, 1000), (512, 4096)),    # chunks larger than the image
-                                          ((1, 96, 1016), (32, 248))])      # aligned rows, an edge cut inside a 16-byte group
+                                          ((1, 96, 1016), (32, 248)),       # aligned rows, an edge cut inside a 16-byte group
+                                          ((2, 257, 515), (64, 128)),       # odd row length: 16-byte loads at 2-byte alignment
+                                          ((1, 70, 37), (16, 8))])          # one 16-byte group per chunk row
 def test_chunk_layout_matches_numpy(shape, chunk):
     import torch
     rng = np.random.default_rng(7)
