@@ -509,7 +509,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * (t_reg + t_fuse) / args.steps, 3),
             "higher_is_better": True,
-            "scaling": "strong" if (strong and world > 1) else "weak",
+            "scaling": args.scaling,   # the series this line belongs to: N = 1 is the first point of either
             "vs_baseline": None,
             "dtype": "f64" if args.fft == "f64" else "f32",
             "data": "synthetic",

@@ -98,8 +98,11 @@ __host__ __device__ __forceinline__ int spectrum_pitch(int L) {
 // the memory system can batch them.
 // Largest radix of the long-axis plans: complex128 lines run radix-8 passes (one more pass,
 // but 90 instead of 154 VGPRs: five waves per SIMD instead of three), complex64 ones radix 16.
+#ifndef MS_LONG_RADIX_F64
+#define MS_LONG_RADIX_F64 8
+#endif
 template <typename T>
-constexpr int kLongMaxRadix = sizeof(T) == 8 ? 8 : 16;
+constexpr int kLongMaxRadix = sizeof(T) == 8 ? MS_LONG_RADIX_F64 : 16;
 
 // Column pass: complex128 blocks run 512 lanes with radix-8 plans (under 128 VGPRs, four waves
 // per SIMD), complex64 ones 256 lanes with radix 16 (their LDS footprint already allows four
