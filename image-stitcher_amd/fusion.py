@@ -208,6 +208,40 @@ class TileInfo:
         return int(m.group(1))
 
 
+def select_z_layers(strategy, num_z: int) -> list:
+    """The z levels a strategy keeps, as ``create_z_layer_selector(strategy).select_z_layers(metadata, num_z)``
+    answers (z_layer_selection.py:52-136, :158-200): "all" -> every level, "middle" -> ``[num_z // 2]``
+    (ValueError for num_z <= 0), an int or a digit string -> that level (ValueError outside
+    ``0 .. num_z - 1``); an unknown string raises ValueError, any other type TypeError.  The result is what
+    ``stitch_region(selected_z=...)`` takes."""
+    if isinstance(strategy, bool) or not isinstance(strategy, (int, str)):
+        raise TypeError(f"Invalid type for z-layer selection strategy: {type(strategy)}. Expected int or str.")
+    if isinstance(strategy, str) and strategy.isdigit():
+        strategy = int(strategy)
+    if isinstance(strategy, int):
+        if strategy < 0 or strategy >= num_z:
+            raise ValueError(f"Z-layer index {strategy} is out of range. Valid range is 0 to {num_z - 1}")
+        return [strategy]
+    if strategy == "all":
+        return list(range(num_z))
+    if strategy == "middle":
+        if num_z <= 0:
+            raise ValueError(f"Invalid number of z-layers: {num_z}")
+        return [num_z // 2]
+    raise ValueError(f"Unknown z-layer selection strategy: {strategy}. Available strategies: ['all', 'middle'] or a numeric index")
+
+
+def z_selection_name(strategy) -> str:
+    """The name the reference's selector reports (``get_name``, z_layer_selection.py:77-78, :99-100, :131-132)."""
+    if isinstance(strategy, str) and strategy.isdigit():
+        strategy = int(strategy)
+    if isinstance(strategy, int) and not isinstance(strategy, bool):
+        return f"specific_layer_{strategy}"
+    if strategy in ("all", "middle"):
+        return {"all": "all_layers", "middle": "middle_layer"}[strategy]
+    raise ValueError(f"Unknown z-layer selection strategy: {strategy}")
+
+
 def stitch_region(tiles, infos: Sequence[TileInfo], channel_names: Sequence[str], px_um: float,
                   flatfields: Optional[Dict[int, np.ndarray]] = None, apply_flatfield: bool = False,
                   selected_z: Optional[Sequence[int]] = None, mode: str = "overwrite",
