@@ -140,6 +140,7 @@ class RegistrationShard:
         self.pair_lists = [cut(r)[0] for r in range(world)]
         self.counts = [len(m) for m in self.pair_lists]
         self.pair_ids, self.tile_ids = cut(rank)
+        self._gather_ws = {}
 
     def local_pairs(self, local_ids) -> np.ndarray:
         """This rank's pairs with tile indices renumbered into ``local_ids`` (sorted global ids of the
@@ -153,15 +154,42 @@ class RegistrationShard:
     def gather(self, out_local, status_local):
         """Rows of every rank in global pair order: the one exchange of the path (an all-gather of
         24 bytes + 1 byte per pair); with one rank, or outside a process group, a plain reorder."""
+        import torch
         import torch.distributed as dist
 
         if self.world > 1:
             if not (dist.is_available() and dist.is_initialized()):
                 raise RuntimeError("world > 1 needs an initialised process group")
-            rows, st = all_gather_pair_results(out_local, status_local, self.counts)
-        else:
-            rows, st = out_local, status_local
-        return scatter_to_global(self.pair_lists, rows, st, self.n_pairs)
+            if dist.get_backend() != "nccl":
+                rows, st = all_gather_pair_results(out_local, status_local, self.counts)
+                return scatter_to_global(self.pair_lists, rows, st, self.n_pairs)
+            # RCCL: the buffers and the two index tables are built once per device and reused, so that a step
+            # is two small copies, two collectives and two indexed writes, with no allocation in between
+            dev = out_local.device
+            ws = self._gather_ws.get(dev)
+            if ws is None:
+                pmax = max(self.counts)
+                src = np.concatenate([r * pmax + np.arange(c) for r, c in enumerate(self.counts)])   # valid slots of [world, pmax]
+                dst = np.concatenate([np.asarray(m) for m in self.pair_lists])                     # their global pair ids
+                ws = dict(pmax=pmax,
+                          pad_out=torch.full((pmax, 3), float("nan"), dtype=torch.float64, device=dev),
+                          pad_st=torch.ones((pmax,), dtype=torch.int8, device=dev),
+                          all_out=torch.empty((self.world * pmax, 3), dtype=torch.float64, device=dev),
+                          all_st=torch.empty((self.world * pmax,), dtype=torch.int8, device=dev),
+                          src=torch.as_tensor(src, dtype=torch.long, device=dev),
+                          dst=torch.as_tensor(dst, dtype=torch.long, device=dev),
+                          rows=torch.full((self.n_pairs, 3), float("nan"), dtype=torch.float64, device=dev),
+                          st=torch.ones((self.n_pairs,), dtype=torch.int8, device=dev))
+                self._gather_ws[dev] = ws
+            n = int(out_local.shape[0])
+            ws["pad_out"][:n] = out_local
+            ws["pad_st"][:n] = status_local
+            dist.all_gather_into_tensor(ws["all_out"], ws["pad_out"])
+            dist.all_gather_into_tensor(ws["all_st"], ws["pad_st"])
+            ws["rows"].index_copy_(0, ws["dst"], ws["all_out"].index_select(0, ws["src"]))
+            ws["st"].index_copy_(0, ws["dst"], ws["all_st"].index_select(0, ws["src"]))
+            return ws["rows"], ws["st"]    # reused by the next call on this device
+        return scatter_to_global(self.pair_lists, out_local, status_local, self.n_pairs)
 
 
 class FusionShard:
