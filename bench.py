@@ -545,7 +545,9 @@ def main():
             "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
             "traffic_source": traffic_note,
             "kernels": {n: {**{k: round(v, 3) for k, v in kernels[n].items()},
-                            **({"hbm_frac": rooflines[n]["frac"]} if n in rooflines else {})} for n in kernels},
+                            **({"hbm_frac": rooflines[n]["frac"]} if n in rooflines else {}),
+                            **({"traffic_over_algorithmic": round(rooflines[n]["traffic"] / rooflines[n]["algorithmic_bytes_per_launch"], 3)}
+                               if n in rooflines and rooflines[n].get("traffic") else {})} for n in kernels},
         }
         if shares is not None:
             line["ranks"] = shares
