@@ -24,6 +24,7 @@ FFT_F64, FFT_F32 = 0, 1
 REG_SUBPIXEL = 2
 REG_PEAKS10 = 4
 REG_WINDOW_HANN = 8
+REG_CONSENSUS = 16
 FUSE_OVERWRITE, FUSE_FEATHER = 0, 1
 FF_NONE, FF_F32, FF_F64 = 0, 1, 2
 

@@ -510,7 +510,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
                                            const void* __restrict__ flatfields,
                                            const int32_t* __restrict__ tile_ff, const int32_t* __restrict__ bins,
                                            uint16_t* __restrict__ mosaic, int Hm, int Wm, int row0, int row1, int gx,
-                                           int gy, int n_planes) {
+                                           int gy, int n_planes, int64_t idle_off, int64_t idle_foff) {
   constexpr int kQueue = kBH * 64 * GX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) queue_len[0] = queue_len[1] = 0;
@@ -608,11 +608,12 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
       k = (!inside | generic_only) ? 2 : k;
       k = outside ? 3 : k;
       kinds |= (unsigned)k << (2 * r);
-      // copy loads never sit behind a branch: lanes without a plain copy read tile 0's first pixels
+      // copy loads never sit behind a branch: lanes without a plain copy read tile 0's first pixels (idle_off = 0;
+      // the host points both idle offsets at the workspace when the tile or flatfield array holds fewer than 8 values)
       const TileRef* c = list + (idx[r] & 31u);
       const int64_t at = yW + x;
-      const int64_t off = k == 1 ? c->src_base + at : 0;
-      const int64_t foff = k == 1 ? c->ff_base + at : 0;
+      const int64_t off = k == 1 ? c->src_base + at : idle_off;
+      const int64_t foff = k == 1 ? c->ff_base + at : idle_foff;
       v[r] = *reinterpret_cast<const Px8*>(tiles + off);
       if constexpr (FF == MISTITCH_FF_F32)
         f32[r] = *reinterpret_cast<const F8*>(reinterpret_cast<const char*>(flatfields) + foff * (int64_t)ffsize);
@@ -710,19 +711,21 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
                                                        const int32_t* __restrict__ bins,
                                                        const int32_t* __restrict__ ff_safe,
                                                        uint16_t* __restrict__ mosaic, int Hm, int Wm, int row0,
-                                                       int row1, int gx, int gy, int n_planes) {
+                                                       int row1, int gx, int gy, int n_planes, int64_t idle_off,
+                                                       int64_t idle_foff) {
   __shared__ TileRef list[kMaxCand];
   __shared__ unsigned queue[kBH * 64 * GX];
   __shared__ unsigned queue_len[3];  // blend entries, pixel-by-pixel entries, candidates with a flatfield plane
   if constexpr (FF == MISTITCH_FF_F32) {
     if (*ff_safe) {
       fuse_block<MODE, FF, GX, true>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
-                                     flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes);
+                                     flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes, idle_off,
+                                     idle_foff);
       return;
     }
   }
   fuse_block<MODE, FF, GX, false>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
-                                  flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes);
+                                  flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff);
 }
 
 // Are all float32 flatfield values that this call uses finite and within [2^-16, 2^16]?
@@ -890,12 +893,12 @@ template <int MODE, int FF, int GX>
 static void launch_fuse(mistitch_ctx* ctx, dim3 grid, const uint16_t* tiles, int n_tiles, int H, int W, int64_t pitch,
                         const int32_t* yx, const int32_t* plane, const void* ffs, const int32_t* tff,
                         const int32_t* bins, const int32_t* ff_safe, uint16_t* mosaic, int Hm, int Wm, int row0,
-                        int row1) {
+                        int row1, int64_t idle_off, int64_t idle_foff) {
   const int gx = (int)grid.x, gy = (int)grid.y, n_planes = (int)grid.z;
   const unsigned n_wg = 8u * gx * (unsigned)((gy * n_planes + 7) / 8);
   MS_LAUNCH(ctx, MODE == MISTITCH_FUSE_OVERWRITE ? "k_fuse_overwrite" : "k_fuse_feather", (k_fuse<MODE, FF, GX>),
             dim3(n_wg), dim3(kFuseThreads), 0, tiles, n_tiles, H, W, pitch, yx, plane, ffs, tff, bins, ff_safe, mosaic,
-            Hm, Wm, row0, row1, gx, gy, n_planes);
+            Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff);
 }
 
 }  // namespace mistitch
@@ -940,10 +943,17 @@ static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int 
   MS_REQUIRE(mode == MISTITCH_FUSE_OVERWRITE || mode == MISTITCH_FUSE_FEATHER, MISTITCH_ERR_ARG, "unknown mode %d", mode);
   MS_REQUIRE(ff_type == MISTITCH_FF_NONE || ff_type == MISTITCH_FF_F32 || ff_type == MISTITCH_FF_F64, MISTITCH_ERR_ARG,
              "unknown flatfield type %d", ff_type);
-  if (ff_type != MISTITCH_FF_NONE)
+  if (ff_type != MISTITCH_FF_NONE && n_tiles > 0)
     MS_REQUIRE(flatfields && tile_ff, MISTITCH_ERR_ARG, "flatfield type given without flatfields / tile_ff");
   if (row1 == row0) return MISTITCH_OK;
   MS_HIP(hipSetDevice(ctx->device));
+  if (n_tiles == 0) {
+    // no tile reaches the band: it is what the reference's zero-initialised output array holds (stitcher.py:154-181);
+    // the fusion kernels, whose idle lanes read the first tile's pixels, are not launched on an empty tile array
+    MS_HIP(hipMemset2DAsync(mosaic + (int64_t)row0 * mosaic_w, (size_t)mosaic_h * mosaic_w * sizeof(uint16_t), 0,
+                            (size_t)(row1 - row0) * mosaic_w * sizeof(uint16_t), (size_t)n_planes, ctx->stream));
+    return MISTITCH_OK;
+  }
   const int GX = ff_type == MISTITCH_FF_NONE ? kGxPlain : kGxFlat;
   const dim3 grid(((mosaic_w + 7 + 7) / 8 + 64 * GX - 1) / (64 * GX), (row1 - row0 + kBH - 1) / kBH, n_planes);
   MS_REQUIRE((int64_t)grid.x * grid.y * grid.z < (1ll << 30), MISTITCH_ERR_UNSUPPORTED, "mosaic too large for one launch");
@@ -972,9 +982,22 @@ static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int 
   if (ff_type == MISTITCH_FF_F32 && n_tiles > 0)
     MS_LAUNCH(ctx, "k_ff_check", k_ff_check, dim3(kFfChunks, kFfPlanes), dim3(256), 0,
               reinterpret_cast<const float*>(flatfields), tile_ff, n_tiles, (int64_t)tile_h * tile_w, ff_safe);
+  // Lanes of k_fuse without a plain copy still issue their 16-byte pixel load (and 32- or 64-byte flatfield load), at
+  // the start of the tile / flatfield array.  An array of fewer than 8 values does not hold such a load: the idle
+  // loads then go to the workspace instead (at least 148 bytes, 16-byte aligned), addressed relative to the arrays.
+  int64_t idle_off = 0, idle_foff = 0;
+  const size_t ff_elem = ff_type == MISTITCH_FF_F64 ? 8 : 4;
+  if ((int64_t)(n_tiles - 1) * tile_pitch + (int64_t)tile_h * tile_w < 8) {
+    MS_REQUIRE((reinterpret_cast<uintptr_t>(tiles) & 1u) == 0, MISTITCH_ERR_ARG, "tiles is not 2-byte aligned");
+    idle_off = (int64_t)(reinterpret_cast<intptr_t>(ws) - reinterpret_cast<intptr_t>(tiles)) / 2;
+  }
+  if (ff_type != MISTITCH_FF_NONE && (int64_t)tile_h * tile_w < 8) {
+    MS_REQUIRE(reinterpret_cast<uintptr_t>(flatfields) % ff_elem == 0, MISTITCH_ERR_ARG, "flatfields is not aligned to its element size");
+    idle_foff = (int64_t)(reinterpret_cast<intptr_t>(ws) - reinterpret_cast<intptr_t>(flatfields)) / (int64_t)ff_elem;
+  }
 #define MS_FUSE(M, F)                                                                                          \
   launch_fuse<M, F, (F == MISTITCH_FF_NONE ? kGxPlain : kGxFlat)>(ctx, grid, tiles, n_tiles, tile_h, tile_w, tile_pitch, tile_yx, tile_plane, flatfields, tile_ff, \
-                    bins, ff_safe, mosaic, mosaic_h, mosaic_w, row0, row1)
+                    bins, ff_safe, mosaic, mosaic_h, mosaic_w, row0, row1, idle_off, idle_foff)
   if (mode == MISTITCH_FUSE_OVERWRITE) {
     if (ff_type == MISTITCH_FF_NONE) MS_FUSE(MISTITCH_FUSE_OVERWRITE, MISTITCH_FF_NONE);
     else if (ff_type == MISTITCH_FF_F32) MS_FUSE(MISTITCH_FUSE_OVERWRITE, MISTITCH_FF_F32);

@@ -2307,11 +2307,25 @@ __device__ double ncc_from_moments(unsigned long long n, unsigned long long sa, 
 // (`wide`: the 160-candidate set of that stage is in use, :1197-1230).
 // `table` (optional): [n_pairs][n_cand][3] = y, x, ncc of every candidate in evaluation order, strip relative;
 // ncc NaN where the reference does not score the candidate (empty overlap).
+//
+// `consensus` (only with the 160-candidate set): the consensus stage itself as the reference runs it when
+// scikit-image's ransac raises on its model class (ransac_translation_estimation, :1085-1127): among the candidates
+// of finite NCC, in evaluation order, the first one with the most neighbours within 2 pixels (Euclidean, itself
+// included) is that stage's result when those neighbours are at least 0.3 of the candidates; otherwise, and with
+// fewer than 3 candidates (:1030-1038), the first candidate of the largest NCC.  The result list is then
+// (consensus stage, subpixel estimate, two-peak discrete search) and the first of the largest NCC wins (:1313).
+constexpr int kConsensusMinSamples = 3;          // RANSACConfig.min_samples (:74)
+constexpr int kConsensusThreshold2 = 4;          // residual_threshold = 2.0, squared (:75; integer shifts: exact)
+constexpr double kConsensusMinInlierRatio = 0.3;  // min_inlier_ratio (:78)
+constexpr int kConsensusFar = 20000;             // row of a candidate that does not take part: no neighbour of any shift
 __global__ __launch_bounds__(256) void k_finalize(const PairDesc* desc, const int8_t* status_in, int n_pairs,
                                                   const Cand* cand, const unsigned long long* acc, double* out,
                                                   int8_t* status, const UpsState* ups, int n_cand, int wide,
-                                                  double* table) {
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                  double* table, int consensus) {
+  __shared__ int s_y[4][kNumCandWide], s_x[4][kNumCandWide];
+  __shared__ double s_v[4][kNumCandWide];
+  const int wv = threadIdx.x >> 6;
+  const int p = blockIdx.x * 4 + wv;
   const int lane = threadIdx.x & 63;
   if (p >= n_pairs) return;
   const double nan = __longlong_as_double(0x7ff8000000000000ll);
@@ -2351,6 +2365,12 @@ __global__ __launch_bounds__(256) void k_finalize(const PairDesc* desc, const in
         row[1] = (double)k.x;
         row[2] = evaluated ? v : nan;
       }
+      if (consensus) {  // only candidates of finite NCC reach the consensus stage (:985-986)
+        const bool finite = evaluated && v != -INFINITY;
+        s_y[wv][ci] = finite ? k.y : kConsensusFar;
+        s_x[wv][ci] = finite ? k.x : 0;
+        s_v[wv][ci] = finite ? v : -INFINITY;
+      }
     }
     double chunk_best = evaluated ? v : -INFINITY;
 #pragma unroll
@@ -2365,6 +2385,52 @@ __global__ __launch_bounds__(256) void k_finalize(const PairDesc* desc, const in
     }
   }
   double oy = any ? (double)by : 0.0, ox = any ? (double)bx : 0.0;
+  double m3 = -INFINITY;  // consensus mode: the two-peak discrete search, listed last
+  int m3y = 0, m3x = 0;
+  if (consensus) {
+    __builtin_amdgcn_wave_barrier();  // the wave's own LDS writes above are read below, by other lanes
+    int n_finite = 0, key_best = -1;
+    for (int c0 = 0; c0 < n_cand; c0 += 64) {
+      const int ci = c0 + lane;
+      int count = 0;
+      bool finite = false;
+      if (ci < n_cand) {
+        const int y = s_y[wv][ci], x = s_x[wv][ci];
+        finite = y != kConsensusFar;
+        if (finite) {
+          for (int j = 0; j < n_cand; ++j) {
+            const int dy = y - s_y[wv][j], dx = x - s_x[wv][j];
+            count += (dy * dy + dx * dx <= kConsensusThreshold2) ? 1 : 0;
+          }
+        }
+      }
+      n_finite += __popcll(__ballot(finite));
+      // most neighbours first, then the earliest candidate (numpy.argmax)
+      key_best = max(key_best, finite ? count * 256 + (255 - ci) : -1);
+    }
+    static_assert(kNumCandWide <= 256, "candidate index packed into 8 bits");
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) key_best = max(key_best, __shfl_xor(key_best, off));
+    if (n_finite >= kConsensusMinSamples) {
+      const int count = key_best >> 8, idx = 255 - (key_best & 255);
+      if (!((double)count / (double)n_finite < kConsensusMinInlierRatio)) {  // the consensus stands
+        best = s_v[wv][idx];
+        oy = (double)s_y[wv][idx];
+        ox = (double)s_x[wv][idx];
+      }
+    }
+    const double mine = lane < kNumCand ? s_v[wv][lane] : -INFINITY;
+    double top = mine;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) top = fmax(top, __shfl_xor(top, off));
+    const unsigned long long at_top = __ballot(mine == top && top != -INFINITY);
+    if (at_top) {
+      const int win = __builtin_ctzll(at_top);
+      m3 = top;
+      m3y = s_y[wv][win];
+      m3x = s_x[wv][win];
+    }
+  }
   const bool has_ups = ups != nullptr && ups[p].valid;
   if (has_ups) {
     const Cand ku = my_cand[n_cand];
@@ -2376,6 +2442,11 @@ __global__ __launch_bounds__(256) void k_finalize(const PairDesc* desc, const in
         ox = d.transposed ? ups[p].sub_s : ups[p].sub_l;
       }
     }
+  }
+  if (m3 > best) {  // (consensus mode) the discrete search only wins with a strictly larger NCC: it is listed last
+    best = m3;
+    oy = (double)m3y;
+    ox = (double)m3x;
   }
   if (lane == 0) {
     out[3 * p] = best;
@@ -3367,7 +3438,7 @@ extern "C" int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int 
   const int64_t slot_elems = 2 * std::max((int64_t)w_left * tile_h, (int64_t)w_top * tile_w);
   const int stage_slots = stage_all_pairs(ctx, max_pairs, chunk, slot_elems) ? max_pairs : chunk;
   if ((rc = reserve_registration(ctx, max_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws,
-                                 (flags & MISTITCH_REG_PEAKS10) ? kNumCandWide : kNumCand)))
+                                 (flags & (MISTITCH_REG_PEAKS10 | MISTITCH_REG_CONSENSUS)) ? kNumCandWide : kNumCand)))
     return rc;
   // Whatever else a first call sets up (tables of the subpixel stage, kernels that need their LDS limit
   // raised) is set up by making that call: max_pairs pairs of two blank tiles, left and top alternating.
@@ -3437,7 +3508,8 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
   const int stage_slots = stage_all ? n_pairs : chunk;
   // peaks the candidate search consumes: 2 (the reference's discrete search), or 10 (the candidate set of its
   // consensus stage, generate_translation_candidates at _translation_computation.py:876-994)
-  const bool wide = (flags & MISTITCH_REG_PEAKS10) != 0;
+  const bool consensus = (flags & MISTITCH_REG_CONSENSUS) != 0;  // the consensus stage works on the ten-peak set
+  const bool wide = (flags & MISTITCH_REG_PEAKS10) != 0 || consensus;
   const int k = wide ? 10 : 2;
   static_assert(kNumCand == 16 * 2 && kNumCandWide == 16 * 10, "16 signed interpretations per peak");
   if ((rc = reserve_registration(ctx, n_pairs, chunk, stage_slots, (size_t)slot_elems, spec, slab, pstride, &ws, 16 * k)))
@@ -3527,7 +3599,8 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
   }
   if (stage_all) candidates(0, n_pairs);
   MS_LAUNCH(ctx, "k_finalize", k_finalize, dim3((n_pairs + 3) / 4), dim3(256), 0, ws.desc, status, n_pairs, ws.cand, ws.acc,
-                     out, status, subpixel ? ws.ups : (const UpsState*)nullptr, ws.n_cand, wide ? 1 : 0, table);
+                     out, status, subpixel ? ws.ups : (const UpsState*)nullptr, ws.n_cand, wide ? 1 : 0, table,
+                     consensus ? 1 : 0);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }

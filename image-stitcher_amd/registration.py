@@ -16,8 +16,8 @@ from typing import Dict, List, Optional, Sequence, Set, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import (FFT_F32, FFT_F64, PAIR_FEATURELESS, PAIR_NO_CANDIDATE, PAIR_OK, REG_PEAKS10, REG_SUBPIXEL,
-                   REG_WINDOW_HANN, check, lib, ptr)
+from ._lib import (FFT_F32, FFT_F64, PAIR_FEATURELESS, PAIR_NO_CANDIDATE, PAIR_OK, REG_CONSENSUS, REG_PEAKS10,
+                   REG_SUBPIXEL, REG_WINDOW_HANN, check, lib, ptr)
 
 logger = logging.getLogger(__name__)
 
@@ -80,7 +80,7 @@ def to_device_u16(arr, device=None):
 def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WIDTH, fft: str = "f64",
                    ctx: Optional[_lib.Context] = None, out=None, status=None, subpixel: bool = False,
                    upsample_factor: int = 100, flatfield=None, peaks10: bool = False, return_candidates: bool = False,
-                   window: Optional[str] = None):
+                   window: Optional[str] = None, consensus: bool = False):
     """Register every (first, second) tile pair on the device.
 
     tiles     [N, H, W] uint16 CUDA tensor (or NumPy array, uploaded)
@@ -98,6 +98,10 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
     ``peaks10``: walk the 16 interpretations of the ten best peaks, the candidate set of the
     reference's consensus stage (generate_translation_candidates(n=10),
     _translation_computation.py:876-994) with its best-NCC fallback (:1112-1118) as the result.
+    ``consensus`` (implies ``peaks10``): the consensus stage over those candidates as the reference runs it
+    (the deterministic neighbour-count clustering of ransac_translation_estimation,
+    _translation_computation.py:1085-1127), its result listed before the subpixel estimate and the
+    two-peak discrete search (:1195-1313).
     ``window="hann"``: both strips are multiplied by a separable Hann window before the transforms (own
     extension, off by default: the reference applies none); the candidate NCCs stay on raw pixels.
     ``return_candidates``: also return the table [P, 32 or 160, 3] (y, x, ncc; strip relative) of
@@ -127,6 +131,9 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
         flags |= REG_SUBPIXEL
     if peaks10:
         flags |= REG_PEAKS10
+    if consensus:
+        flags |= REG_CONSENSUS | REG_PEAKS10
+        peaks10 = True
     ff, ff_type = None, _lib.FF_NONE
     if flatfield is not None:
         ff = flatfield if isinstance(flatfield, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(flatfield))

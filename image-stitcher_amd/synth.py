@@ -21,6 +21,17 @@ def make_scene(seed: int, height: int, width: int) -> np.ndarray:
     return (1000.0 + 30000.0 * rng.random((height, width))).astype(np.uint16)
 
 
+def lowpass_scene(scene: np.ndarray, strength: float) -> np.ndarray:
+    """Gaussian low-pass of a scene in the frequency domain, ``exp(-strength * |f|^2)`` with f in cycles per
+    pixel, stretched back to 1000 .. 51000.  Smooth scenes rank many near-equal correlation peaks: the input on
+    which the ten-peak candidate set and its consensus stage differ from the two-peak search."""
+    h, w = scene.shape
+    f = np.fft.fft2(scene.astype(np.float64))
+    k = np.fft.fftfreq(h)[:, None] ** 2 + np.fft.fftfreq(w)[None, :] ** 2
+    low = np.fft.ifft2(f * np.exp(-k * float(strength))).real
+    return (1000 + 50000 * (low - low.min()) / (low.max() - low.min())).astype(np.uint16)
+
+
 def make_flatfield(height: int, width: int, dtype=np.float32, amplitude: float = 0.2) -> np.ndarray:
     """Smooth illumination profile ``1 + a cos(pi u) cos(pi v)``, mean-normalised."""
     u = np.linspace(-0.5, 0.5, height, dtype=np.float64)[:, None]
@@ -64,14 +75,17 @@ def grid_pairs(rows: int, cols: int) -> Tuple[np.ndarray, np.ndarray]:
 
 def make_grid(seed: int, rows: int, cols: int, tile_h: int, tile_w: int,
               overlap: float = 0.10, jitter: int = 3,
-              scene: Optional[np.ndarray] = None) -> SyntheticGrid:
-    """Cut a ``rows x cols`` grid of tiles with integer position jitter from a scene."""
+              scene: Optional[np.ndarray] = None, lowpass: float = 0.0) -> SyntheticGrid:
+    """Cut a ``rows x cols`` grid of tiles with integer position jitter from a scene (white noise, or with
+    ``lowpass`` > 0 its low-passed version, see ``lowpass_scene``)."""
     pitch_y = tile_h - int(round(tile_h * overlap))
     pitch_x = tile_w - int(round(tile_w * overlap))
     sh = (rows - 1) * pitch_y + tile_h + 2 * jitter
     sw = (cols - 1) * pitch_x + tile_w + 2 * jitter
     if scene is None:
         scene = make_scene(seed, sh, sw)
+        if lowpass > 0:
+            scene = lowpass_scene(scene, lowpass)
     rng = np.random.default_rng(seed + 7919)
     jit = rng.integers(-jitter, jitter + 1, size=(rows * cols, 2)) if jitter > 0 \
         else np.zeros((rows * cols, 2), dtype=np.int64)

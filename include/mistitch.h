@@ -42,6 +42,8 @@ extern "C" {
 #define MISTITCH_FFT_F32 1u /* complex64 spectra: half the traffic, PCM differs at ~1e-7     */
 #define MISTITCH_REG_SUBPIXEL 2u /* mistitch_register_pairs: add the upsampled-DFT estimate    */
 #define MISTITCH_REG_PEAKS10 4u  /* mistitch_register_pairs: search the 10 best peaks (160 candidates) */
+#define MISTITCH_REG_CONSENSUS 16u /* mistitch_register_pairs: the consensus stage over those 160 candidates (implies
+                                      MISTITCH_REG_PEAKS10), see mistitch_register_pairs_candidates */
 #define MISTITCH_REG_WINDOW_HANN 8u /* registration, mistitch_pcm*, mistitch_subpixel_shift: multiply both strips
                                        by a separable symmetric Hann window (numpy.hanning along either axis, in
                                        float64) before the transforms; the candidate NCCs stay on raw pixels.
@@ -96,10 +98,11 @@ int mistitch_reserve_registration(mistitch_ctx* ctx, int tile_h, int tile_w, int
  * Replaces the serial pair loop of process_neighborhood_batch
  * (tile_registration.py:310-378) and, per pair, compute_single_translation
  * (tile_registration.py:527-586): featureless test, phase correlation, peak
- * ranking, 16-candidate NCC search over the two best peaks.  Results equal the
- * reference's only where its RANSAC branch (interpret_translation_ransac "Method 1",
- * _translation_computation.py:1197-1230, needs scikit-image) is inactive; with that
- * branch active the reference may return a consensus shift instead: parity unpinned.
+ * ranking, 16-candidate NCC search over the two best peaks.  That is what the
+ * reference computes where scikit-image is not installed (its import guard,
+ * _translation_computation.py:13-22, then skips "Method 1" and "Method 2" of
+ * interpret_translation_ransac, :1197-1272); MISTITCH_REG_CONSENSUS and
+ * MISTITCH_REG_SUBPIXEL add those two methods.
  *
  *   tiles      [n_tiles] images of tile_h x tile_w uint16, row-major, image t at
  *              tiles + t * tile_pitch (elements)
@@ -143,10 +146,23 @@ int mistitch_register_pairs_flatfield(mistitch_ctx* ctx, const uint16_t* tiles, 
  * largest PCM peaks instead of two: the candidate set of the reference's "Method 1"
  * (generate_translation_candidates(n=10), _translation_computation.py:876-994), whose
  * best-NCC candidate is what that method returns whenever its consensus step declines
- * (ransac_translation_estimation, :1019-1038 and :1112-1118).  The consensus step itself
- * (scikit-image's ransac on an unseeded random state, :1077-1084) is not reproduced.  The
+ * (ransac_translation_estimation, :1019-1038 and :1112-1118).  The
  * result is the first candidate of the walk that no other beats; with MISTITCH_REG_SUBPIXEL
  * as well the subpixel estimate only wins when strictly better (Method 1 is listed first).
+ *
+ * Flag MISTITCH_REG_CONSENSUS (implies MISTITCH_REG_PEAKS10): the consensus step of "Method 1" as
+ * the reference executes it.  ransac_translation_estimation hands skimage.measure.ransac a model
+ * class whose estimate(self, data, *args) unpacks `src, dst = data` (:1053-1055); ransac calls
+ * estimate(*samples) with a 3-row sample (min_samples = 3, :74), the unpacking raises, and the
+ * reference's own `except` branch (:1085-1107) decides, deterministically: pairwise Euclidean
+ * distances of the candidates of finite NCC, neighbours within residual_threshold = 2.0 (the
+ * candidate itself included), the FIRST candidate with the most neighbours; when those neighbours are
+ * fewer than min_inlier_ratio = 0.3 of the candidates (:1110-1118), or the candidates fewer than 3
+ * (:1030-1038), the first candidate of the largest NCC instead.  Its shift, scored at that
+ * position (:1217-1227), heads the result list, then the subpixel estimate (MISTITCH_REG_SUBPIXEL),
+ * then the two-peak discrete search (:1276-1280); the first entry of the largest NCC is returned
+ * (:1313).  A scikit-image whose ransac does NOT raise on that model class would draw random samples
+ * from an unseeded generator instead: that behaviour is not reproduced (parity unpinned there).
  *
  * mistitch_register_pairs_candidates: mistitch_register_pairs (flatfield == NULL, ff_type
  * MISTITCH_FF_NONE) or mistitch_register_pairs_flatfield, plus the table the walk scored:

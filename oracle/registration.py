@@ -290,6 +290,78 @@ def register_pairs_peaks10(tiles: np.ndarray, pair_idx, directions: Sequence[int
 
 
 # ----------------------------------------------------------------------------
+# a-7  "Method 1", the consensus step as the reference executes it     tc:997-1140, 1197-1230
+# ----------------------------------------------------------------------------
+CONSENSUS_MIN_SAMPLES = 3          # RANSACConfig.min_samples, tc:74
+CONSENSUS_THRESHOLD = 2.0          # residual_threshold, tc:75 and tr:573
+CONSENSUS_MIN_INLIER_RATIO = 0.3   # min_inlier_ratio, tc:78 and tr:573
+
+
+def consensus_translation(translations: np.ndarray, scores: np.ndarray):
+    """(ncc, y, x, used_consensus) of ``ransac_translation_estimation`` + the re-scoring at tc:1217-1227, or None.
+
+    The reference hands ``skimage.measure.ransac`` a model class whose ``estimate(self, data, *args)`` unpacks
+    ``src, dst = data`` (tc:1053-1055).  ``ransac`` calls ``estimate(*samples)``, so ``data`` is the 3-row sample of
+    ``src`` alone (min_samples = 3), the unpacking raises, and the reference's own ``except`` branch decides
+    (tc:1085-1107): pairwise Euclidean distances, neighbours within the residual threshold (the candidate itself
+    counts), the FIRST candidate with the most neighbours.  Fewer neighbours than ``min_inlier_ratio`` of the
+    candidates (tc:1110-1118) or fewer than ``min_samples`` candidates (tc:1030-1038): the first candidate of the
+    largest NCC.  The chosen shift is integer valued, so the NCC at its rounded position is its own score.
+    """
+    n = len(translations)
+    if n == 0:
+        return None
+    pick, used = int(np.argmax(scores)), False
+    if n >= CONSENSUS_MIN_SAMPLES:
+        t = np.asarray(translations, dtype=np.float64)
+        diff = t[:, None, :] - t[None, :, :]
+        dist = np.sqrt((diff * diff).sum(axis=2))
+        neighbours = np.sum(dist <= CONSENSUS_THRESHOLD, axis=1)
+        centre = int(np.argmax(neighbours))
+        if not (int(neighbours[centre]) / n < CONSENSUS_MIN_INLIER_RATIO):
+            pick, used = centre, True
+    return float(scores[pick]), float(translations[pick][0]), float(translations[pick][1]), used
+
+
+def compute_translation_consensus(strip1, strip2, yins, xins, ymin, ymax, xmin, xmax, n: int = 10):
+    """The reference's result list with its consensus stage live and no subpixel stage: (method 1, discrete
+    search); the first of equal scores wins (tc:1195-1230, 1274-1313).  The polish (tc:1285-1307) returns its start
+    point and loses the tie, so it is left out here as in ``compute_translation(polish=False)``."""
+    results = []
+    t, sc = generate_translation_candidates(strip1, strip2, yins, xins, ymin, ymax, xmin, xmax, n)
+    m1 = consensus_translation(t, sc)
+    if m1 is not None and ymin <= m1[1] <= ymax and xmin <= m1[2] <= xmax and np.isfinite(m1[0]):
+        results.append(m1[:3])
+    d = interpret_translation(strip1, strip2, yins, xins, ymin, ymax, xmin, xmax, min(int(n), 2))
+    if d[0] != float("-inf"):
+        results.append((d[0], float(d[1]), float(d[2])))
+    if not results:
+        return float("-inf"), 0.0, 0.0
+    return max(results, key=lambda r: r[0])
+
+
+def register_pairs_consensus(tiles: np.ndarray, pair_idx, directions: Sequence[int], edge_width: int):
+    """``register_pairs`` with the consensus stage live; also returns per pair whether the consensus stood."""
+    pair_idx = np.asarray(pair_idx).reshape(-1, 2)
+    out = np.full((len(pair_idx), 3), np.nan, dtype=np.float64)
+    status = np.zeros(len(pair_idx), dtype=np.int8)
+    stood = []
+    for p, (i1, i2) in enumerate(pair_idx):
+        e1, e2, off_y, off_x = edge_strips(tiles[i1], tiles[i2], "top" if directions[p] else "left", edge_width)
+        if e1.size == 0 or e2.size == 0 or min(e1.shape) < 2 or is_edge_featureless(e1) or is_edge_featureless(e2):
+            status[p] = 1
+            stood.append(None)
+            continue
+        eh, ew = e1.shape
+        yins, xins, _ = multi_peak_max(pcm(e1, e2))
+        m1 = consensus_translation(*generate_translation_candidates(e1, e2, yins, xins, -eh, eh, -ew, ew, 10))
+        stood.append(None if m1 is None else m1[3])
+        score, y, x = compute_translation_consensus(e1, e2, yins, xins, -eh, eh, -ew, ew, 10)
+        out[p] = (score, y + off_y, x + off_x)
+    return out, status, stood
+
+
+# ----------------------------------------------------------------------------
 # a-8  bounded least-squares polish                               tc:1466-1588
 # ----------------------------------------------------------------------------
 def optimize_translation_continuous(strip1, strip2, y0: float, x0: float,

@@ -312,3 +312,45 @@ def test_mip_known_answers_of_the_reference_tests(fu):
     im = _np(fu.stitch_region(tiles, infos, ["DAPI"], 20.0, apply_mip=True))
     assert im.shape == (1, 1, 1, 100, 100)
     assert im[0, 0, 0, 0, 0] == 2 and im[0, 0, 0, 0, 50] == 5 and im[0, 0, 0, 50, 0] == 8 and im[0, 0, 0, 99, 99] == 11
+
+
+@pytest.mark.parametrize("static_workspace", [False, True])
+@pytest.mark.parametrize("mode", ["overwrite", "feather"])
+@pytest.mark.parametrize("with_ff", [False, True])
+def test_fusing_no_tiles_zeroes_the_band_and_nothing_else(fu, mode, static_workspace, with_ff):
+    """Zero tiles (a NULL tile array): the band is what the reference's zero-initialised output holds
+    (stitcher.py:154-181), rows outside the band keep the caller's contents; both entry points."""
+    import torch
+    mh, mw, planes = 300, 1037, 2
+    out = torch.full((planes, mh, mw), 0x5a5a, dtype=torch.int16, device="cuda").view(torch.uint16)
+    empty = torch.empty((0, 64, 64), dtype=torch.int16, device="cuda").view(torch.uint16)
+    assert empty.data_ptr() == 0
+    ffs = np.ones((1, 64, 64), dtype=np.float32) if with_ff else None
+    tff = np.zeros((0,), dtype=np.int32) if with_ff else None
+    got = fu.fuse_tiles(empty, np.zeros((0, 2), np.int32), np.zeros((0,), np.int32), planes, mh, mw, flatfields=ffs,
+                        tile_ff=tff, mode=mode, rows=(40, 173), out=out, static_workspace=static_workspace)
+    got = _np(got)
+    assert (got[:, 40:173] == 0).all()
+    assert (got[:, :40] == 0x5a5a).all() and (got[:, 173:] == 0x5a5a).all()
+
+
+def test_stitch_region_of_a_z_level_no_tile_has(fu):
+    """selected_z names a level without tiles: the reference's loop places nothing and returns zeros."""
+    infos = [fu.TileInfo(f"R0_{i}_0_c.tiff", 0.1 * i, 0.0, 0, "c") for i in range(3)]
+    tiles = np.full((3, 32, 32), 7, dtype=np.uint16)
+    out = _np(fu.stitch_region(tiles, infos, ["c"], 1.0, selected_z=[5]))
+    assert out.shape[:3] == (1, 1, 1) and (out == 0).all()
+
+
+@pytest.mark.parametrize("mode", ["overwrite", "feather"])
+@pytest.mark.parametrize("with_ff", [False, True])
+def test_a_tile_array_smaller_than_one_16_byte_load(fu, mode, with_ff):
+    """One 2 x 3 tile (12 bytes; its flatfield plane 24 bytes): no lane may read 16 bytes at the array's start."""
+    tiles = np.array([[[10, 20, 30], [40, 50, 60]]], dtype=np.uint16)
+    yx, plane = np.array([[1, 2]], np.int32), np.zeros(1, np.int32)
+    ffs = np.array([[[1.0, 2.0, 0.5], [4.0, 1.0, 1.0]]], dtype=np.float32) if with_ff else None
+    tff = np.zeros(1, np.int32) if with_ff else None
+    oracle = ofu.fuse_overwrite if mode == "overwrite" else ofu.fuse_feather
+    ref = oracle(tiles, yx, plane, 1, 5, 9, flatfields=ffs, tile_ff=tff)
+    got = _np(fu.fuse_tiles(tiles, yx, plane, 1, 5, 9, flatfields=ffs, tile_ff=tff, mode=mode))
+    assert np.array_equal(got, ref)

@@ -171,3 +171,54 @@ def test_method1_candidates_match_the_reference():
             assert len(tables[p][1]) == exp["n"]
             assert tuple(out[p, 1:]) == tuple(exp["fallback"][1:]) and abs(out[p, 0] - exp["fallback"][0]) < 1e-12
             assert abs(float(np.sum(tables[p][1])) - exp["score_sum"]) < 1e-9
+
+
+def _consensus_golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "consensus_golden.json")) as fh:
+        return json.load(fh)
+
+
+def consensus_strips(s):
+    """The strip pair of one consensus_golden.json case, as tests/golden/make_golden_consensus.py builds it."""
+    h, w = s["shape"]
+    dy, dx = s["shift"]
+    big = synth.make_scene(s["seed"], h + 64, w + 64)
+    if s["lowpass"]:
+        f = np.fft.fft2(big.astype(np.float64))
+        k = np.fft.fftfreq(h + 64)[:, None] ** 2 + np.fft.fftfreq(w + 64)[None, :] ** 2
+        low = np.fft.ifft2(f * np.exp(-k * float(s["lowpass"]))).real
+        big = (1000 + 50000 * (low - low.min()) / (low.max() - low.min())).astype(np.uint16)
+    return (np.ascontiguousarray(big[32:32 + h, 32:32 + w]),
+            np.ascontiguousarray(big[32 + dy:32 + dy + h, 32 + dx:32 + dx + w]))
+
+
+def test_consensus_step_matches_the_reference():
+    """The consensus step of the reference's Method 1 (the clustering branch its own code takes when scikit-image's
+    ransac raises on its model class), restated in the oracle, against vectors made by running that branch of the
+    reference (tests/golden/make_golden_consensus.py)."""
+    doc = _consensus_golden()
+    for t in doc["tables"]:
+        got = oreg.consensus_translation(np.array(t["translations"]).reshape(-1, 2), np.array(t["scores"]))
+        assert [got[1], got[2]] == t["best"], t["name"]
+    kinds = set()
+    for s in doc["strips"]:
+        a, b = consensus_strips(s)
+        h, w = s["shape"]
+        yi, xi, _ = oreg.multi_peak_max(oreg.pcm(a, b))
+        tr_, sc = oreg.generate_translation_candidates(a, b, yi, xi, -h, h, -w, w, 10)
+        assert len(sc) == s["n"]
+        m1 = oreg.consensus_translation(tr_, sc)
+        assert [m1[1], m1[2]] == s["method1"] and m1[3] == s["stood"], s
+        got = oreg.compute_translation_consensus(a, b, yi, xi, -h, h, -w, w, 10)
+        assert [got[1], got[2]] == s["final"][1:] and abs(got[0] - s["final"][0]) < 1e-12, s
+        kinds.add(s["kind"])
+    assert kinds == {"stands_wins", "stands_loses", "declined"}
+    for g in doc["grids"]:
+        grid = synth.make_grid(g["seed"], g["rows"], g["cols"], g["tile_h"], g["tile_w"], overlap=g["overlap"], jitter=g["jitter"])
+        out, status, _ = oreg.register_pairs_consensus(grid.tiles, grid.pair_idx, grid.pair_dir, g["edge_width"])
+        for p, exp in enumerate(g["pairs"]):
+            assert (exp is None) == (status[p] != 0), (g["name"], p)
+            if exp is not None:
+                assert tuple(out[p, 1:]) == tuple(exp[1:]) and abs(out[p, 0] - exp[0]) < 1e-12, (g["name"], p)

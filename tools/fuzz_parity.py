@@ -182,6 +182,27 @@ def fuzz_peaks10(rng, reg, oreg, synth):
     return bool(good), dict(kind="peaks10", grid=(rows, cols), tile=(th, tw), edge=edge), (out, st, exp, exp_st)
 
 
+def fuzz_consensus(rng, reg, oreg, synth):
+    """The consensus stage (MISTITCH_REG_CONSENSUS) against the oracle's statement of the reference's clustering
+    branch; small tiles and narrow strips, where many of the 160 candidates coincide and the consensus stands."""
+    rows, cols = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+    if rows * cols == 1:
+        cols = 2
+    th, tw = (int(rng.choice([16, 24, 32, 64, 128, int(rng.integers(16, 120))])) for _ in range(2))
+    edge = int(rng.choice([4, 6, 8, 12, 16, 32, int(rng.integers(4, 40))]))
+    g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, th, tw, overlap=float(rng.uniform(0.1, 0.3)),
+                        jitter=int(rng.integers(1, 4)), lowpass=float(rng.choice([0, 200, 2000, 8000])))
+    out, st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, consensus=True)
+    out, st = out.cpu().numpy(), st.cpu().numpy()
+    exp, exp_st, stood = oreg.register_pairs_consensus(g.tiles, g.pair_idx, g.pair_dir, edge)
+    STATS["consensus_stood"] = STATS.get("consensus_stood", 0) + sum(1 for v in stood if v)
+    STATS["consensus_pairs"] = STATS.get("consensus_pairs", 0) + sum(1 for v in stood if v is not None)
+    good = bool(np.array_equal(st != 0, exp_st != 0))
+    ok = exp_st == 0
+    good = good and np.array_equal(out[ok, 1:], exp[ok, 1:]) and np.allclose(out[ok, 0], exp[ok, 0], rtol=0, atol=1e-9)
+    return bool(good), dict(kind="consensus", grid=(rows, cols), tile=(th, tw), edge=edge), (out, st, exp, exp_st)
+
+
 def fuzz_window(rng, reg, oreg, synth):
     """The Hann window option against the oracle's NumPy statement of it."""
     rows, cols = (1, 2) if rng.random() < 0.5 else (2, 1)
@@ -465,7 +486,8 @@ def main():
                "fusion_ff_extreme": lambda: fuzz_fusion_ff_extreme(rng, fu, ofu, synth),
                "mixed_radix": lambda: fuzz_mixed_radix(rng, reg, oreg, synth),
                "peaks10": lambda: fuzz_peaks10(rng, reg, oreg, synth),
-               "window": lambda: fuzz_window(rng, reg, oreg, synth)}
+               "window": lambda: fuzz_window(rng, reg, oreg, synth),
+               "consensus": lambda: fuzz_consensus(rng, reg, oreg, synth)}
     kinds = [k for k in runners if not args.only or k in args.only.split(",")]
     counts = {k: 0 for k in kinds}
     last = t0
@@ -475,7 +497,7 @@ def main():
         counts[kind] += 1
         if not good:
             print("DISAGREEMENT", desc, flush=True)
-            if kind in ("registration", "subpixel", "refine", "registration_big", "registration_tiny", "featureless", "registration_wild", "mixed_radix", "peaks10", "window") or desc.get("api") in ("ncc", "pcm_topk"):
+            if kind in ("registration", "subpixel", "refine", "registration_big", "registration_tiny", "featureless", "registration_wild", "mixed_radix", "peaks10", "window", "consensus") or desc.get("api") in ("ncc", "pcm_topk"):
                 out, st, exp, exp_st = data
                 print(np.concatenate([out, st[:, None], exp, exp_st[:, None]], axis=1))
             else:
