@@ -26,6 +26,7 @@
 
 #include "common.hpp"
 #include "fft.hpp"
+#include "fft_reg.hpp"
 
 namespace mistitch {
 
@@ -685,6 +686,57 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
   MS_STAMP(0, 3);
 }
 
+// The same pass for complex128 lines of N = 512 .. 4096 points on the register-resident engine (fft_reg.hpp): a
+// lane takes its 8 pixels of either strip straight from memory (a wave reads 128 contiguous bytes per
+// instruction), the twiddle bases come from the plan's table of roots with the same round trip, and the only
+// LDS traffic is the exchanges between the radix passes and the transposition in front of the slab stores.
+// grid (S, pairs_in_pass), N / 8 lanes, one line per workgroup.
+template <int N, bool WIN>
+__global__ __launch_bounds__(N / 8) void k_fft_long_fwd_reg(const PairDesc* desc, const int8_t* status, int pair0, int S,
+                                                            int want_transposed, const double2* __restrict__ roots,
+                                                            double2* slabs, const double* __restrict__ win_s,
+                                                            const double* __restrict__ win_l) {
+  using F = RegFft<N>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double2* buf = reinterpret_cast<double2*>(smem_raw);
+  const int p = pair0 + blockIdx.y;
+  const int8_t pair_status = status[p];
+  const PairDesc d = desc[p];
+  const int t = threadIdx.x, w = t >> 6, l = t & 63;
+  const int s = blockIdx.x;
+  // every load that depends on nothing but the descriptor goes out together
+  const typename F::Tw tw = F::load_twiddles(roots, t);
+  if (pair_status != MISTITCH_PAIR_OK || d.S != S || d.L != N || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  const uint16_t* ra = d.a + (int64_t)s * d.pitch + t;
+  const uint16_t* rb = d.b + (int64_t)s * d.pitch + t;
+  unsigned pa[8], pb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    pa[j] = ra[F::NL * j];
+    pb[j] = rb[F::NL * j];
+  }
+  double2 v[8];
+  if constexpr (WIN) {
+    const double ws = win_s[s];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double wgt = ws * win_l[t + F::NL * j];
+      v[j] = mk<double>((double)pa[j] * wgt, (double)pb[j] * wgt);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = mk<double>((double)pa[j], (double)pb[j]);
+  }
+  F::forward(v, buf, tw, t);
+  // the wave's own 512 storage positions, 64 consecutive ones per trip: 8 lanes fill one 128-byte slab piece
+  double2* out = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, N) + (int64_t)s * kSlab;
+  const int64_t sp = slab_pitch(S);
+  const double2* from = buf + F::slot(w * 512 + l);
+  double2* to = out + (int64_t)(w * 64 + (l >> 3)) * sp + (l & 7);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) to[(int64_t)(8 * i) * sp] = from[72 * i];
+}
+
 template <typename T>
 __device__ __forceinline__ T cabs_safe(T x, T y);
 template <>
@@ -876,6 +928,144 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
     MS_STAMP(1, 4);
   }
   MS_STAMP(1, 5);
+}
+
+// The column pass for complex128 columns of S = 128 or 256 rows with every radix pass in registers (the scheme of
+// fft_reg.hpp along the short axis).  A unit is 8 stored columns and the 8 columns of their negated frequencies:
+// lanes [0, S) take the stored columns, lanes [S, 2S) the others, lane (c, q) = (lane & 7, lane / 8) holding 8 rows of
+// column c.  In memory a unit's 8 columns are ONE contiguous [S][8] block of the slab buffer, so a wave's loads cover
+// 8 whole rows (1 KiB).  The passes (S / 64, 8, 8) exchange through LDS (row r of a half at slot r + r / 8, rows of
+// 128 bytes: conflict free for the row sets of every pass); the forward transform's last pass leaves a lane the 8
+// storage positions that the inverse transform's first pass starts from, so the cross-power stage works on registers
+// and only reads the partner cells from LDS.  The second half's waves leave once their transform is published.
+// grid (n_units, pairs_in_pass), 2 S lanes.
+template <int S>
+__global__ __launch_bounds__(2 * S, 4) void k_fft_short_cps_reg(const PairDesc* desc, const int8_t* status, int pair0, int L,
+                                                             int want_transposed, const double2* __restrict__ roots,
+                                                             const uint16_t* __restrict__ mpos_s,
+                                                             const uint16_t* __restrict__ pos2freq_s,
+                                                             const uint16_t* __restrict__ mpos_l,
+                                                             const CpsUnit* __restrict__ units, const double2* slabs,
+                                                             double2* spectrum, double eps, double2* keep_r,
+                                                             const uint16_t* __restrict__ pos2stored, int n_stored) {
+  constexpr int Q = S / 8;            // lanes per column
+  constexpr int R0 = S / 64;          // radix of the first pass
+  constexpr int NB = 8 / R0;          // its butterflies per lane
+  constexpr int kRows = S + S / 8;    // slots of a half
+  static_assert(S == 128 || S == 256, "passes (S / 64, 8, 8)");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double2* buf = reinterpret_cast<double2*>(smem_raw);
+  const int p = pair0 + blockIdx.y;
+  const int8_t pair_status = status[p];
+  const int d_S = desc[p].S, d_L = desc[p].L, d_transposed = desc[p].transposed;
+  const CpsUnit un = units[blockIdx.x];
+  const int tid = threadIdx.x;
+  const int half = tid >= S ? 1 : 0, lt = tid - half * S;
+  const int c = lt & 7, q = lt >> 3;
+  const bool single = un.nb == 0;  // the stored columns hold their own negated frequencies: the second half repeats them
+  const int pos = (half == 0 || single ? un.a0 : un.b0) + c;
+  const int64_t sp = slab_pitch(S);
+  const double2* src = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L) + (pos / kSlab) * sp + pos % kSlab;
+  double2 v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = src[(q + Q * j) * kSlab];
+  double2 tw0[NB];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) tw0[k] = roots[q + k * Q];
+  const double2 tw1 = roots[(q & 7) * (S / 64)];
+  const int mp = mpos_l[un.a0 + c];
+  const uint4 mrow4 = *reinterpret_cast<const uint4*>(mpos_s + 8 * q);       // partner rows of rows 8 q .. 8 q + 7
+  const int col0 = pos2stored[un.a0];
+  if (pair_status != MISTITCH_PAIR_OK) return;
+  if (d_S != S || d_L != L || (want_transposed >= 0 && d_transposed != want_transposed)) return;
+  double2* mine = buf + half * (kRows * 8);
+  // first pass: rows q + Q j
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    double2 x[R0];
+#pragma unroll
+    for (int m = 0; m < R0; ++m) x[m] = v[k + NB * m];
+    RegFft<512>::butterfly<R0, false>(x, tw0[k], true);
+#pragma unroll
+    for (int m = 0; m < R0; ++m) v[k + NB * m] = x[m];
+  }
+  auto slot = [](int r) { return r + (r >> 3); };
+  double2* at_a = mine + slot(q) * 8 + c;                          // rows q + Q j
+  double2* at_b = mine + slot((q >> 3) * 64 + (q & 7)) * 8 + c;    // rows (q / 8) 64 + q % 8 + 8 m
+  double2* at_c = mine + 9 * q * 8 + c;                            // rows 8 q + m
+#pragma unroll
+  for (int j = 0; j < 8; ++j) at_a[j * (Q + Q / 8) * 8] = v[j];
+  lds_barrier();
+#pragma unroll
+  for (int m = 0; m < 8; ++m) v[m] = at_b[9 * m * 8];
+  RegFft<512>::butterfly<8, false>(v, tw1, true);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) at_b[9 * m * 8] = v[m];  // in place: the slots this lane has just read
+  lds_barrier();
+#pragma unroll
+  for (int m = 0; m < 8; ++m) v[m] = at_c[m * 8];
+  RegFft<512>::butterfly<8, false>(v, mk<double>(1.0, 0.0), false);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) at_c[m * 8] = v[m];
+  lds_barrier();
+  if (half == 1) return;  // whole waves: the barriers below count the surviving ones
+  // normalised cross-power spectrum of the two strips packed in z = A + i B (see k_fft_short_cps)
+  const double2* partner = buf + (single ? 0 : kRows * 8) + (single ? mp - un.a0 : mp - un.b0);
+  const unsigned mrow[8] = {mrow4.x & 0xffffu, mrow4.x >> 16, mrow4.y & 0xffffu, mrow4.y >> 16,
+                            mrow4.z & 0xffffu, mrow4.z >> 16, mrow4.w & 0xffffu, mrow4.w >> 16};
+#pragma unroll
+  for (int h = 0; h < 8; h += 4) {  // four cells at a time: their partner reads in flight together
+    double2 zm[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) zm[m] = partner[slot((int)mrow[h + m]) * 8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const double2 z = v[h + m];
+      const double ax = 0.5 * (z.x + zm[m].x), ay = 0.5 * (z.y - zm[m].y);
+      const double bx = 0.5 * (z.y + zm[m].y), by = -0.5 * (z.x - zm[m].x);
+      double fx = ax * bx + ay * by;  // A * conj(B)
+      double fy = ay * bx - ax * by;
+      const double inv = 1.0 / (cabs_safe<double>(fx, fy) + eps);
+      v[h + m] = mk<double>(fx * inv, fy * inv);
+    }
+  }
+  if (keep_r != nullptr) {
+    // the subpixel stage's copy replaces this unit's own slab, rows reordered to ascending signed frequency
+    const uint4 frow4 = *reinterpret_cast<const uint4*>(pos2freq_s + 8 * q);  // frequencies of rows 8 q .. 8 q + 7
+    const unsigned frow[8] = {frow4.x & 0xffffu, frow4.x >> 16, frow4.y & 0xffffu, frow4.y >> 16,
+                              frow4.z & 0xffffu, frow4.z >> 16, frow4.w & 0xffffu, frow4.w >> 16};
+    double2* Rs = keep_r + (int64_t)blockIdx.y * slab_pair_elems(S, L) + (pos / kSlab) * sp + pos % kSlab;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) Rs[(int)((frow[m] + S / 2) & (S - 1)) * kSlab] = v[m];
+  }
+  // inverse transform of the stored columns: the first adjoint pass starts from the rows a lane holds
+  RegFft<512>::butterfly<8, true>(v, mk<double>(1.0, 0.0), false);
+  if (single) lds_barrier();  // the partner cells lie in this half: every lane has to have read them (workgroup uniform)
+#pragma unroll
+  for (int m = 0; m < 8; ++m) at_c[m * 8] = v[m];
+  lds_barrier();
+#pragma unroll
+  for (int m = 0; m < 8; ++m) v[m] = at_b[9 * m * 8];
+  RegFft<512>::butterfly<8, true>(v, tw1, true);
+#pragma unroll
+  for (int m = 0; m < 8; ++m) at_b[9 * m * 8] = v[m];  // in place
+  lds_barrier();
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = at_a[j * (Q + Q / 8) * 8];
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    double2 x[R0];
+#pragma unroll
+    for (int m = 0; m < R0; ++m) x[m] = v[k + NB * m];
+    RegFft<512>::butterfly<R0, true>(x, tw0[k], true);
+#pragma unroll
+    for (int m = 0; m < R0; ++m) v[k + NB * m] = x[m];
+  }
+  // natural order out: rows q + Q j of the packed intermediate spectrum, 8 columns = 128 bytes per row
+  const int Lp = spectrum_pitch<double>(n_stored);
+  double2* Z = spectrum + (int64_t)blockIdx.y * S * Lp + col0 + c;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) Z[(int64_t)(q + Q * j) * Lp] = v[j];
 }
 
 // Inverse FFT along the long axis, two lines per complex transform, then the
@@ -1110,6 +1300,162 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
     __syncthreads();
   }
   MS_STAMP(2, 3);
+}
+
+// The production case of that pass (two peaks at most, no correlation plane wanted) for complex128 lines of
+// N = 512 .. 4096 points on the register-resident engine: the stored half of two spectrum rows is spread over the
+// line in LDS as before, the adjoint passes run in registers, and the values are ranked where the last pass
+// leaves them.  grid (ceil(nblk / seq), pairs_in_pass), N / 8 lanes, blocks of two lines (nblk per strip).
+template <int N, bool ABS>
+__global__ __launch_bounds__(N / 8, 4) void k_fft_long_inv_reg(const PairDesc* desc, const int8_t* status, int pair0, int S,
+                                                            int want_transposed, const double2* __restrict__ roots,
+                                                            const uint16_t* __restrict__ stored_pos,
+                                                            const uint16_t* __restrict__ mirror_fill, int n_stored,
+                                                            const double2* spectrum, int k, Peak* partial,
+                                                            int partial_stride, Peak* partial_abs, int abs_stride,
+                                                            int nblk, int seq) {
+  using F = RegFft<N>;
+  constexpr int NT = N / 8, NW = NT / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double2* buf = reinterpret_cast<double2*>(smem_raw);
+  __shared__ Peak red[2 * NW];
+  const int p = pair0 + blockIdx.y;
+  const int8_t pair_status = status[p];
+  const PairDesc d = desc[p];
+  const int tid = threadIdx.x;
+  typename F::Tw tw = F::load_twiddles(roots, tid);
+  const int blk0 = blockIdx.x * seq;
+  int s0 = blk0 * 2;
+  const int Lp = spectrum_pitch<double>(n_stored);
+  const double2* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
+  // lines s0, s0 + 1 into LDS as g1 + i g2; false (for every lane alike) when the pair is not this launch's
+  auto load_lines = [&]() -> bool {
+    constexpr int U = 4;
+    const double2* z1 = Z + (int64_t)min(s0, S - 1) * Lp;      // lines past the last one read it and count as zero
+    const double2* z2 = Z + (int64_t)min(s0 + 1, S - 1) * Lp;
+    for (int e0 = tid; e0 < n_stored; e0 += NT * U) {
+      double2 g1[U], g2[U];
+      uint16_t at_pos[U], at_mir[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = min(e0 + u * NT, n_stored - 1);  // clamp, do not branch around the loads
+        g1[u] = z1[i];
+        g2[u] = z2[i];
+        at_pos[u] = stored_pos[i];
+        at_mir[u] = mirror_fill[i];
+      }
+      if (pair_status != MISTITCH_PAIR_OK || d.S != S || d.L != N || (want_transposed >= 0 && d.transposed != want_transposed))
+        return false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        MS_PIN(g1[u].x); MS_PIN(g1[u].y);
+        MS_PIN(g2[u].x); MS_PIN(g2[u].y);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (e0 + u * NT < n_stored) {
+          const int pos = at_pos[u], mir = at_mir[u];
+          if (s0 >= S) g1[u] = mk<double>(0.0, 0.0);
+          if (s0 + 1 >= S) g2[u] = mk<double>(0.0, 0.0);
+          buf[F::slot(pos)] = mk<double>(g1[u].x - g2[u].y, g1[u].y + g2[u].x);  // g1 + i g2
+          if (mir != 0xffff) buf[F::slot(mir)] = mk<double>(g1[u].x + g2[u].y, g2[u].x - g1[u].y);  // conj(g1) + i conj(g2)
+        }
+      }
+    }
+    return true;
+  };
+  if (!load_lines()) return;
+  __syncthreads();
+  const double scale = 1.0 / ((double)S * (double)N);
+  // values are compared unscaled where the scale is a power of two, scaled otherwise (see k_fft_long_inv)
+  const bool exact_scale = (S & (S - 1)) == 0;
+  const double cmp_scale = exact_scale ? 1.0 : scale;
+  const double out_scale = exact_scale ? scale : 1.0;
+  double v1 = -INFINITY, v2 = -INFINITY;
+  int k1 = -1, k2 = -1;
+  Peak ba{-INFINITY, -1, -1};  // largest magnitude, first in row-major order (subpixel stage only)
+  auto offer = [&](double v, int key, bool have) {
+    const bool gt1 = have & ((v > v1) | ((v == v1) & (key > k1)));
+    const bool gt2 = have & ((v > v2) | ((v == v2) & (key > k2)));
+    v2 = gt1 ? v1 : (gt2 ? v : v2);
+    k2 = gt1 ? k1 : (gt2 ? key : k2);
+    v1 = gt1 ? v : v1;
+    k1 = gt1 ? key : k1;
+  };
+  constexpr bool want_abs = ABS;  // (partial_abs is given exactly then)
+  for (int it = 0;;) {
+    double2 v[8];
+    // the twiddle bases are pinned per trip: their powers are then formed where they are used, not hoisted out of
+    // the loop and kept (80 registers) across it
+#pragma unroll
+    for (int kk = 0; kk < F::NB; ++kk) {
+      MS_PIN(tw.p0[kk].x);
+      MS_PIN(tw.p0[kk].y);
+    }
+    MS_PIN(tw.p1.x); MS_PIN(tw.p1.y);
+    MS_PIN(tw.p2.x); MS_PIN(tw.p2.y);
+    F::inverse(v, buf, tw, tid);
+    const bool have0 = s0 < S, have1 = s0 + 1 < S;  // an odd S leaves the last transform half empty
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int l = tid + NT * j;
+      const int key0 = d.transposed ? l * S + s0 : s0 * N + l;
+      const int key1 = d.transposed ? key0 + 1 : key0 + N;
+      offer(v[j].x * cmp_scale, key0, have0);
+      offer(v[j].y * cmp_scale, key1, have1);
+      if (want_abs) {
+        const double a0v = fabs(v[j].x * scale), a1v = fabs(v[j].y * scale);
+        const bool t0 = have0 & first_better(a0v, key0, ba.val, ba.key);
+        ba.val = t0 ? a0v : ba.val;
+        ba.key = t0 ? key0 : ba.key;
+        const bool t1 = have1 & first_better(a1v, key1, ba.val, ba.key);
+        ba.val = t1 ? a1v : ba.val;
+        ba.key = t1 ? key1 : ba.key;
+      }
+    }
+    s0 += 2;
+    if (++it >= seq || s0 >= S) break;  // the same for every lane
+    __syncthreads();                    // the last pass has read the line that the next one replaces
+    load_lines();
+    __syncthreads();
+  }
+  ba.loc = ba.key >= 0 ? 0 : -1;
+  Peak b1{k1 >= 0 ? v1 * out_scale : -INFINITY, k1, k1}, b2{k2 >= 0 ? v2 * out_scale : -INFINITY, k2, k2};
+  const Peak none{-INFINITY, -1, -1};
+  if constexpr (ABS) {
+    const Peak best = block_argmax_first<NW>(ba, red);
+    if (tid == 0) partial_abs[(int64_t)blockIdx.y * abs_stride + blk0] = best;
+    if (tid > 0 && tid < seq && blk0 + tid < nblk) partial_abs[(int64_t)blockIdx.y * abs_stride + blk0 + tid] = none;
+    __syncthreads();
+  }
+  const Peak w1 = wave_best_peak(b1, peak_better);
+  if (w1.loc >= 0 && w1.loc == b1.loc) b1 = b2;
+  const Peak w2 = k > 1 ? wave_best_peak(b1, peak_better) : none;
+  if ((tid & 63) == 0) {
+    red[2 * (tid >> 6)] = w1;
+    red[2 * (tid >> 6) + 1] = w2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    Peak t1 = none, t2 = none;
+#pragma unroll
+    for (int e = 0; e < 2 * NW; ++e) {
+      const Peak o = red[e];
+      if (peak_better(o.val, o.key, t1.val, t1.key)) {
+        t2 = t1;
+        t1 = o;
+      } else if (peak_better(o.val, o.key, t2.val, t2.key)) {
+        t2 = o;
+      }
+    }
+    Peak* dst = partial + (int64_t)blockIdx.y * partial_stride + blk0 * k;
+    dst[0] = t1;
+    if (k > 1) dst[1] = t2;
+  } else if (tid < seq && blk0 + tid < nblk) {  // the list entries of the other blocks this workgroup covered
+    Peak* dst = partial + (int64_t)blockIdx.y * partial_stride + (blk0 + tid) * k;
+    dst[0] = none;
+    if (k > 1) dst[1] = none;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2748,6 +3094,7 @@ struct ShapeCfg {
   GenPlanDev gpS;   // the chirp-z plan of the short axis then (planS unused)
   FftPlanDev planS, planL;
   int C;       // columns per block of the column pass (LDS rows hold 2C)
+  bool reg_cols;  // every unit is 8 stored columns, alone or with the 8 of their negated frequencies (k_fft_short_cps_reg)
   const CpsUnit* units;    // device
   int n_units;
   const uint16_t* stored_pos;   // device: positions k_fft_short_cps wrote, ascending
@@ -2823,6 +3170,8 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
   }
   MS_REQUIRE(C >= 1, MISTITCH_ERR_UNSUPPORTED, "no column-pass decomposition for long side %d", L);
   cfg->C = C;
+  cfg->reg_cols = C == 8;
+  for (const CpsUnit& u : units) cfg->reg_cols = cfg->reg_cols && u.na == 8 && (u.nb == 8 || u.nb == 0);
   if (mixed)
     cfg->lds_cps = ((size_t)S * 2 * C + S) * esz + ((size_t)S * 4 + 15) / 16 * 16;  // columns, all S roots, two index tables
   else if (gen_short)
@@ -3265,6 +3614,44 @@ static int get_hann(mistitch_ctx* ctx, int n, const double** out) {
   return MISTITCH_OK;
 }
 
+// Forward long-axis pass on the register-resident engine, for the line lengths it is built for (complex128 plans
+// whose passes are (L / 512, 8, 8, 8)); *done = false where the caller has to take the in-LDS kernel.
+template <int N>
+static int launch_long_fwd_reg_n(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace& ws, const int8_t* status,
+                                 int pair0, int n, int want_transposed, double2* slabs) {
+  const size_t lds = (size_t)RegFft<N>::kSlots * sizeof(double2);
+  const double2* roots = reinterpret_cast<const double2*>(cfg.planL.tw);
+  int rc;
+  if (ws.window) {
+    const double *win_s = nullptr, *win_l = nullptr;
+    if ((rc = get_hann(ctx, cfg.S, &win_s))) return rc;
+    if ((rc = get_hann(ctx, cfg.L, &win_l))) return rc;
+    if ((rc = allow_lds(ctx, k_fft_long_fwd_reg<N, true>, lds))) return rc;
+    MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd_reg<N, true>), dim3(cfg.S, n), dim3(N / 8), lds, ws.desc, status, pair0,
+              cfg.S, want_transposed, roots, slabs, win_s, win_l);
+  } else {
+    if ((rc = allow_lds(ctx, k_fft_long_fwd_reg<N, false>, lds))) return rc;
+    MS_LAUNCH(ctx, "k_fft_long_fwd", (k_fft_long_fwd_reg<N, false>), dim3(cfg.S, n), dim3(N / 8), lds, ws.desc, status, pair0,
+              cfg.S, want_transposed, roots, slabs, (const double*)nullptr, (const double*)nullptr);
+  }
+  return MISTITCH_OK;
+}
+static int launch_long_fwd_reg(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace& ws, const int8_t* status,
+                               int pair0, int n, int want_transposed, double2* slabs, bool* done) {
+  *done = true;
+  if (kLongMaxRadix<double> == 8 && cfg.S <= 65535) {
+    switch (cfg.L) {
+      case 512: return launch_long_fwd_reg_n<512>(ctx, cfg, ws, status, pair0, n, want_transposed, slabs);
+      case 1024: return launch_long_fwd_reg_n<1024>(ctx, cfg, ws, status, pair0, n, want_transposed, slabs);
+      case 2048: return launch_long_fwd_reg_n<2048>(ctx, cfg, ws, status, pair0, n, want_transposed, slabs);
+      case 4096: return launch_long_fwd_reg_n<4096>(ctx, cfg, ws, status, pair0, n, want_transposed, slabs);
+      default: break;
+    }
+  }
+  *done = false;
+  return MISTITCH_OK;
+}
+
 // The three FFT kernels for pairs [pair0, pair0 + n) of one canonical shape.
 template <typename T>
 static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace& ws, const int8_t* status,
@@ -3272,7 +3659,14 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
   cx<T>* spec = reinterpret_cast<cx<T>*>(ws.spectrum);
   cx<T>* slabs = reinterpret_cast<cx<T>*>(ws.slabs);
   int rc;
-  if (ws.window) {
+  bool fwd_done = false;
+  if constexpr (std::is_same<T, double>::value) {
+    if (!getenv("MISTITCH_FFT_LDS_ENGINE") &&
+        (rc = launch_long_fwd_reg(ctx, cfg, ws, status, pair0, n, want_transposed, slabs, &fwd_done)))
+      return rc;
+  }
+  if (fwd_done) {
+  } else if (ws.window) {
     const double *win_s = nullptr, *win_l = nullptr;
     if ((rc = get_hann(ctx, cfg.S, &win_s))) return rc;
     if ((rc = get_hann(ctx, cfg.L, &win_l))) return rc;
@@ -3314,6 +3708,24 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
       column_pass_done = true;
     }
   }
+  if constexpr (std::is_same<T, double>::value) {
+    if (!column_pass_done && !cfg.gen_short && cfg.reg_cols && (cfg.S == 128 || cfg.S == 256) && kShortMaxRadix<double> == 8 &&
+        !getenv("MISTITCH_FFT_LDS_ENGINE")) {
+      const double2* roots = reinterpret_cast<const double2*>(cfg.planS.tw);
+#define MS_CPS_REG(SS)                                                                                                 \
+  do {                                                                                                                 \
+    const size_t lds = (size_t)2 * (SS + SS / 8) * 8 * sizeof(double2);                                                \
+    if ((rc = allow_lds(ctx, k_fft_short_cps_reg<SS>, lds))) return rc;                                                \
+    MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps_reg<SS>), dim3(cfg.n_units, n), dim3(2 * SS), lds, ws.desc, status, \
+              pair0, cfg.L, want_transposed, roots, cfg.planS.mpos, cfg.planS.pos2freq, cfg.planL.mpos, cfg.units, slabs, \
+              spec, (double)eps, ws.n_up ? slabs : (double2*)nullptr, cfg.pos2stored, cfg.n_stored);                    \
+  } while (0)
+      if (cfg.S == 128) MS_CPS_REG(128);
+      else MS_CPS_REG(256);
+#undef MS_CPS_REG
+      column_pass_done = true;
+    }
+  }
   if (!column_pass_done) {
     MS_REQUIRE(!cfg.gen_short, MISTITCH_ERR_UNSUPPORTED, "a short side of %d needs the complex128 path", cfg.S);
     constexpr int kNT = kShortThreads<T>, kSR = kShortMaxRadix<T>;
@@ -3322,17 +3734,48 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
               status, pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps,
               ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
   }
-  if ((rc = allow_lds(ctx, k_fft_long_inv<T>, cfg.lds_inv))) return rc;
   // Where the last radix pass ranks its values (two peaks, no PCM plane), a workgroup takes several blocks of lines
   // in turn and reduces once - as long as the launch still fills the chip a few times over.
   const int nblk_inv = (cfg.S + 2 * cfg.NF_inv - 1) / (2 * cfg.NF_inv);
   int seq = 1;
   if (k > 0 && k <= 2 && pcm_out == nullptr)
     while (seq < kLongInvSeq && (int64_t)((nblk_inv + 2 * seq - 1) / (2 * seq)) * n >= 2048) seq *= 2;
-  MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv<T>), dim3((nblk_inv + seq - 1) / seq, n), dim3(kThreads), cfg.lds_inv, ws.desc,
-            status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored, cfg.NF_inv,
-            spec, k, ws.partial, ws.partial_stride, pcm_out, ws.n_up ? ws.partial_abs : (Peak*)nullptr, ws.abs_stride,
-            nblk_inv, seq);
+  bool inv_done = false;
+  if constexpr (std::is_same<T, double>::value) {
+    // two peaks at most and no correlation plane: the register-resident engine, for the line lengths it is built for
+    if (k > 0 && k <= 2 && pcm_out == nullptr && cfg.NF_inv == 1 && kLongMaxRadix<double> == 8 && !getenv("MISTITCH_FFT_LDS_ENGINE")) {
+      const double2* roots = reinterpret_cast<const double2*>(cfg.planL.tw);
+      Peak* pabs = ws.n_up ? ws.partial_abs : (Peak*)nullptr;
+#define MS_INV_REG(NN)                                                                                                \
+  do {                                                                                                                \
+    const size_t lds = (size_t)RegFft<NN>::kSlots * sizeof(double2);                                                  \
+    if (pabs != nullptr) {                                                                                            \
+      if ((rc = allow_lds(ctx, k_fft_long_inv_reg<NN, true>, lds))) return rc;                                        \
+      MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv_reg<NN, true>), dim3((nblk_inv + seq - 1) / seq, n), dim3(NN / 8), lds, \
+                ws.desc, status, pair0, cfg.S, want_transposed, roots, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored, \
+                spec, k, ws.partial, ws.partial_stride, pabs, ws.abs_stride, nblk_inv, seq);                          \
+    } else {                                                                                                          \
+      if ((rc = allow_lds(ctx, k_fft_long_inv_reg<NN, false>, lds))) return rc;                                       \
+      MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv_reg<NN, false>), dim3((nblk_inv + seq - 1) / seq, n), dim3(NN / 8), lds, \
+                ws.desc, status, pair0, cfg.S, want_transposed, roots, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored, \
+                spec, k, ws.partial, ws.partial_stride, pabs, ws.abs_stride, nblk_inv, seq);                          \
+    }                                                                                                                 \
+    inv_done = true;                                                                                                  \
+  } while (0)
+      if (cfg.L == 512) MS_INV_REG(512);
+      else if (cfg.L == 1024) MS_INV_REG(1024);
+      else if (cfg.L == 2048) MS_INV_REG(2048);
+      else if (cfg.L == 4096) MS_INV_REG(4096);
+#undef MS_INV_REG
+    }
+  }
+  if (!inv_done) {
+    if ((rc = allow_lds(ctx, k_fft_long_inv<T>, cfg.lds_inv))) return rc;
+    MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv<T>), dim3((nblk_inv + seq - 1) / seq, n), dim3(kThreads), cfg.lds_inv, ws.desc,
+              status, pair0, cfg.S, cfg.L, want_transposed, cfg.planL, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored, cfg.NF_inv,
+              spec, k, ws.partial, ws.partial_stride, pcm_out, ws.n_up ? ws.partial_abs : (Peak*)nullptr, ws.abs_stride,
+              nblk_inv, seq);
+  }
   if (ws.n_up) {
     // subpixel refinement of these pairs, while their normalised spectra still sit in the slab buffer
     UpsTables tabs{cfg.ups_slabs, cfg.n_ups_slabs, cfg.pos2stored, cfg.stored2kappa, cfg.kappa};
