@@ -65,6 +65,10 @@ def parse_args():
     ap.add_argument("--band-align", type=int, default=256,
                     help="mosaic row bands of the ranks are multiples of this many rows (the reference writes chunks of "
                          "min(H, 12288) rows, parameters.py:695-701: a writer gathers whole bands per chunk)")
+    ap.add_argument("--as-rank", type=int, default=None,
+                    help="one-GPU projection of a sharded run: do the work of rank R of --of ranks (its run of pairs, its band "
+                         "of mosaic rows, its resident tiles) without a process group or a collective")
+    ap.add_argument("--of", type=int, default=8, help="ranks of the split that --as-rank takes one of")
     ap.add_argument("--no-side", action="store_true",
                     help="skip the side figures (other fusion mode, other FFT precision): profiler runs")
     return ap.parse_args()
@@ -146,6 +150,8 @@ def cpu_baseline(n_pairs_target, edge_width, tile, fuse_mode, with_ff):
     ff = synth.make_flatfield(tile, tile)
     t0 = time.perf_counter()
     corrected = np.stack([ofu.apply_flatfield(x, ff) for x in g.tiles]) if with_ff else g.tiles
+    t_ff = time.perf_counter() - t0
+    t0 = time.perf_counter()
     out, _ = oreg.register_pairs(corrected, g.pair_idx[:n], g.pair_dir[:n], edge_width, polish=True)
     t_reg = time.perf_counter() - t0
     # all cores: the box gives a one-GPU job 16 CPUs (os.cpu_count() shows the whole machine)
@@ -176,7 +182,7 @@ def cpu_baseline(n_pairs_target, edge_width, tile, fuse_mode, with_ff):
          tile_ff=plane[:nf] if with_ff else None)
     t_fuse = time.perf_counter() - t0
     mpix = union_area(yx[:nf], tile, tile) / 1e6
-    return dict(pairs=n, t_reg=t_reg, t_fuse=t_fuse, fused_mpix=mpix, tiles_fused=nf, grid_side=side,
+    return dict(pairs=n, t_reg=t_reg, t_ff=t_ff, n_tiles=len(g.tiles), t_fuse=t_fuse, fused_mpix=mpix, tiles_fused=nf, grid_side=side,
                 t_reg_procs=t_reg_procs, procs=n_proc)
 
 
@@ -253,6 +259,10 @@ def main():
     # ---- the partition: strong = one acquisition over all ranks, weak = one acquisition per rank ----
     strong = args.scaling == "strong" or world == 1
     part_world, part_rank = (world, rank) if strong else (1, 0)
+    as_rank = args.as_rank is not None
+    if as_rank:
+        assert world == 1 and 0 <= args.as_rank < args.of, "--as-rank is a one-process projection"
+        part_world, part_rank = args.of, args.as_rank
     seed = 3 if strong else 3 + rank
     rows, cols = cfg["rows"], cfg["cols"]
     n_tiles_grid = rows * cols
@@ -305,7 +315,7 @@ def main():
 
     def step_registration():
         register(fft_flag, d_out, d_status)
-        if part_world > 1:   # every rank ends up with every pair row
+        if part_world > 1 and not as_rank:   # every rank ends up with every pair row
             gathered[0], gathered[1] = rs.gather(d_out, d_status)
         else:
             gathered[0], gathered[1] = d_out, d_status
@@ -317,6 +327,11 @@ def main():
     def step_registration_subpixel():
         """The configured step with the upsampled-DFT estimate added for every pair."""
         register(fft_flag | _lib.REG_SUBPIXEL, d_out2, d_status2)
+
+    def step_registration_full():
+        """Every method of the reference's production call (tile_registration.py:568-576 with scikit-image present):
+        the consensus stage over the ten-peak candidate set, the upsampled-DFT estimate, the two-peak discrete search."""
+        register(fft_flag | _lib.REG_CONSENSUS | _lib.REG_PEAKS10 | _lib.REG_SUBPIXEL, d_out2, d_status2)
 
     def fuse(mode):
         if band_h == 0:
@@ -355,7 +370,7 @@ def main():
     t_reg = timed(step_registration, args.steps)
     t_fuse = timed(step_fusion, args.steps)
     # side figures (one-GPU runs): the other fusion mode and the other FFT precision, same bracketing
-    side = not args.no_side and world == 1
+    side = not args.no_side and world == 1 and not as_rank
     if side:
         step_fusion_other()
         t_fuse_other = timed(step_fusion_other, args.steps)
@@ -365,6 +380,9 @@ def main():
         step_registration_subpixel()
         t_reg_sub = timed(step_registration_subpixel, args.steps)
         out3_np = d_out2.cpu().numpy()
+        step_registration_full()
+        t_reg_full = timed(step_registration_full, args.steps)
+        out4_np, st4_np = d_out2.cpu().numpy(), d_status2.cpu().numpy()
         # host-to-device rate of a pinned buffer of tile data (what an ingest stage would pay; never part of `value`)
         n_h2d = min(64, tiles.shape[1])
         pinned = torch.empty((n_h2d, tile, tile), dtype=torch.int16).pin_memory()
@@ -403,7 +421,15 @@ def main():
     torch.cuda.synchronize()
     out_np, st_np = gathered[0].cpu().numpy(), gathered[1].cpu().numpy()
     expected = true_yx[pair_idx[:, 1]] - true_yx[pair_idx[:, 0]]
-    shifts_ok = bool((st_np == 0).all() and np.array_equal(out_np[:, 1:].astype(np.int64), expected))
+    if as_rank:   # this rank's rows only: nothing was gathered
+        shifts_ok = bool((st_np == 0).all() and np.array_equal(out_np[:, 1:].astype(np.int64), expected[rs.pair_ids]))
+        full = np.full((n_pairs_grid, 3), np.nan)
+        full[:, 1:] = expected          # the other ranks' rows, as they would arrive: the solve below is timed on a full table
+        full[:, 0] = 1.0
+        full[rs.pair_ids] = out_np
+        out_np, st_np = full, np.zeros(n_pairs_grid, dtype=np.int8)
+    else:
+        shifts_ok = bool((st_np == 0).all() and np.array_equal(out_np[:, 1:].astype(np.int64), expected))
 
     # ---- the host step between the two device stages: pair rows -> tile positions (never part of `value`) ----
     from image_stitcher_amd import solve
@@ -460,6 +486,20 @@ def main():
                                    frac=round(gbs / HBM_PEAK_GBS, 4), traffic=traffic.get(name),
                                    avg_launch_us=round(k["avg_launch_us"], 2),
                                    algorithmic_bytes_per_launch=int(alg_bytes_per_step[name] / k["launches_per_step"]))
+    # the transform kernels are not bound by HBM alone: their float64 arithmetic against the vector peak, 5 N log2 N
+    # flops per N-point complex transform (lines of `tile` points: `edge` forward, edge / 2 inverse; columns of `edge`
+    # points: `tile` forward, the stored half inverse)
+    FP64_PEAK_TFLOPS = 78.6
+    lg = lambda v: float(np.log2(v))
+    stored = tile // 2 + 8
+    fft_flops_per_pair = {"k_fft_long_fwd": 5.0 * tile * lg(tile) * edge,
+                          "k_fft_short_cps": 5.0 * edge * lg(edge) * (tile + stored),
+                          "k_fft_long_inv": 5.0 * tile * lg(tile) * ((edge + 1) // 2)}
+    for name, fl in fft_flops_per_pair.items():
+        if name in kernels and kernels[name]["ms_per_step"] > 0:
+            tf = n_pairs * fl / (kernels[name]["ms_per_step"] * 1e-3) / 1e12
+            kernels[name]["fp64_tflops"] = tf
+            kernels[name]["fp64_frac"] = tf / FP64_PEAK_TFLOPS
     # the dominant kernel of the configured step (the other fusion mode is a side figure)
     in_step = [n for n in rooflines if n != f"k_fuse_{other_mode}"]
     dominant = max(in_step, key=lambda n: kernels[n]["ms_per_step"]) if in_step else None
@@ -500,6 +540,9 @@ def main():
     if rank == 0:
         part = (f"one acquisition sharded over {world} GPUs: contiguous runs of pairs, mosaic by row bands (multiples of {args.band_align} rows)"
                 if strong and world > 1 else ("one acquisition per GPU" if world > 1 else "one GPU"))
+        if as_rank:
+            part = (f"PROJECTION on one GPU: the share of rank {part_rank} of {part_world} of one sharded acquisition (its pairs, its "
+                    f"mosaic band, its resident tiles), no collective; value = the whole grid's pairs / this rank's time")
         line = {
             "metric": "tile_pairs_registered_per_sec",
             "value": round(pairs_per_s, 1),
@@ -519,7 +562,9 @@ def main():
                        "mosaic_rows_on_rank0": band_h, "tiles_resident_on_rank0": n_local},
             "registration": {"ms_per_step": round(1e3 * t_reg / args.steps, 3),
                              "includes": ("flatfield applied to the edge strips as they are extracted, " if ffs is not None else "")
-                             + "register_pairs" + (", RCCL all-gather of pair rows" if (strong and world > 1) else ""),
+                             + "register_pairs = featureless test, phase correlation, two-peak 32-candidate NCC search (what the "
+                               "reference computes where scikit-image is absent; consensus / subpixel stages: registration_all_methods)"
+                             + (", RCCL all-gather of pair rows" if (strong and world > 1 and not as_rank) else ""),
                              "roofline_whole_path": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                                                      "achieved": round(reg_gbs, 1), "frac": round(reg_gbs / HBM_PEAK_GBS, 4),
                                                      "algorithmic_bytes_per_pair": reg_bytes_per_pair,
@@ -544,13 +589,16 @@ def main():
                                "tree_edges": len(solved.tree)},
             "roofline": dict(rooflines[dominant], kernel=dominant) if dominant else None,
             "traffic_source": traffic_note,
-            "kernels": {n: {**{k: round(v, 3) for k, v in kernels[n].items()},
+            "kernels": {n: {**{k: round(v, 4 if k.startswith("fp64") else 3) for k, v in kernels[n].items()},
                             **({"hbm_frac": rooflines[n]["frac"]} if n in rooflines else {}),
                             **({"traffic_over_algorithmic": round(rooflines[n]["traffic"] / rooflines[n]["algorithmic_bytes_per_launch"], 3)}
                                if n in rooflines and rooflines[n].get("traffic") else {})} for n in kernels},
         }
         if shares is not None:
             line["ranks"] = shares
+        if as_rank:
+            line["as_rank"] = {"rank": part_rank, "of": part_world, "pairs": n_pairs, "mosaic_rows": band_h, "tiles_resident": n_local,
+                               "registration_ms": round(1e3 * t_reg / args.steps, 3), "fusion_ms": round(1e3 * t_fuse / args.steps, 3)}
         if side:
             line["fusion_" + other_mode] = {
                 "value": round(mpix_per_s_other, 1), "unit": "MPix/s",
@@ -575,13 +623,24 @@ def main():
                 "value": round(job_pairs * args.steps / t_reg_sub, 1), "unit": "tile-pairs/s",
                 "ms_per_step": round(1e3 * t_reg_sub / args.steps, 3), "upsample_factor": 100,
                 "max_abs_shift_error_px": float(np.abs(out3_np[:, 1:] - expected).max())}
+            line["registration_all_methods"] = {
+                "value": round(job_pairs * args.steps / t_reg_full, 1), "unit": "tile-pairs/s",
+                "ms_per_step": round(1e3 * t_reg_full / args.steps, 3),
+                "what": "consensus stage over the 160 candidates of the ten best peaks + upsampled-DFT estimate (factor 100) + "
+                        "two-peak discrete search, first of the largest NCC: every method of the reference's production call "
+                        "(tile_registration.py:568-576) when scikit-image is installed; its least-squares polish returns its "
+                        "start point and is not run",
+                "planted_integer_shifts_recovered": bool((st4_np == 0).all() and
+                                                         np.array_equal(np.rint(out4_np[:, 1:]).astype(np.int64), expected))}
         if cpu is not None:
             cpu_pairs_s = cpu["pairs"] / cpu["t_reg"]
             line["cpu_baseline"] = {
                 "value": round(cpu_pairs_s, 3), "unit": "tile-pairs/s", "cores": 1, "kind": "port",
-                "sample": f"{cpu['pairs']} pairs of a {cpu['grid_side']}x{cpu['grid_side']} grid of {tile}^2 tiles "
-                          f"(flatfield + register, NumPy oracle incl. least-squares polish, serial as the reference); "
-                          f"fusion: {cpu['tiles_fused']} tiles, {args.fuse_mode}",
+                "sample": f"{cpu['pairs']} pairs of a {cpu['grid_side']}x{cpu['grid_side']} grid of {tile}^2 tiles, registration only "
+                          f"(tiles already corrected; NumPy oracle: two-peak discrete search + least-squares polish, what the reference "
+                          f"computes without scikit-image; serial as the reference); fusion: {cpu['tiles_fused']} tiles, {args.fuse_mode}",
+                "flatfield_of_whole_tiles": {"tiles": cpu["n_tiles"], "seconds": round(cpu["t_ff"], 3),
+                                             "note": "the reference corrects whole tiles when it loads them; not part of value"},
                 "host_cpus": os.cpu_count(),
                 "all_cores": {"value": round(cpu["pairs"] / cpu["t_reg_procs"], 3), "unit": "tile-pairs/s",
                               "cores": cpu["procs"],

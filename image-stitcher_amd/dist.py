@@ -152,8 +152,9 @@ class RegistrationShard:
         return pos.reshape(-1, 2).astype(np.int32)
 
     def gather(self, out_local, status_local):
-        """Rows of every rank in global pair order: the one exchange of the path (an all-gather of
-        24 bytes + 1 byte per pair); with one rank, or outside a process group, a plain reorder."""
+        """Rows of every rank in global pair order: the one exchange of the path (a single all-gather of
+        32 bytes per pair: ncc, y, x and the status as a fourth float64); with one rank, or outside a process
+        group, a plain reorder.  Over RCCL the result is on the HOST (where the position solve consumes it)."""
         import torch
         import torch.distributed as dist
 
@@ -163,32 +164,33 @@ class RegistrationShard:
             if dist.get_backend() != "nccl":
                 rows, st = all_gather_pair_results(out_local, status_local, self.counts)
                 return scatter_to_global(self.pair_lists, rows, st, self.n_pairs)
-            # RCCL: the buffers and the two index tables are built once per device and reused, so that a step
-            # is two small copies, two collectives and two indexed writes, with no allocation in between
+            # RCCL: ONE collective.  The status rides as a fourth float64 column of the pair rows (32 bytes per
+            # pair); the gathered [world * pmax, 4] block comes to the host in one copy, where the position solve
+            # runs anyway, and is put into global pair order with NumPy: no indexed device kernels, and after the
+            # first call no allocation.  Returned tensors are HOST tensors, reused by the next call.
             dev = out_local.device
             ws = self._gather_ws.get(dev)
             if ws is None:
                 pmax = max(self.counts)
                 src = np.concatenate([r * pmax + np.arange(c) for r, c in enumerate(self.counts)])   # valid slots of [world, pmax]
                 dst = np.concatenate([np.asarray(m) for m in self.pair_lists])                     # their global pair ids
-                ws = dict(pmax=pmax,
-                          pad_out=torch.full((pmax, 3), float("nan"), dtype=torch.float64, device=dev),
-                          pad_st=torch.ones((pmax,), dtype=torch.int8, device=dev),
-                          all_out=torch.empty((self.world * pmax, 3), dtype=torch.float64, device=dev),
-                          all_st=torch.empty((self.world * pmax,), dtype=torch.int8, device=dev),
-                          src=torch.as_tensor(src, dtype=torch.long, device=dev),
-                          dst=torch.as_tensor(dst, dtype=torch.long, device=dev),
-                          rows=torch.full((self.n_pairs, 3), float("nan"), dtype=torch.float64, device=dev),
-                          st=torch.ones((self.n_pairs,), dtype=torch.int8, device=dev))
+                pin = dev.type == "cuda"
+                ws = dict(pmax=pmax, src=src, dst=dst,
+                          pad=torch.full((pmax, 4), float("nan"), dtype=torch.float64, device=dev),
+                          all=torch.empty((self.world * pmax, 4), dtype=torch.float64, device=dev),
+                          host=torch.empty((self.world * pmax, 4), dtype=torch.float64, pin_memory=pin),
+                          rows=torch.full((self.n_pairs, 3), float("nan"), dtype=torch.float64),
+                          st=torch.ones((self.n_pairs,), dtype=torch.int8))
                 self._gather_ws[dev] = ws
             n = int(out_local.shape[0])
-            ws["pad_out"][:n] = out_local
-            ws["pad_st"][:n] = status_local
-            dist.all_gather_into_tensor(ws["all_out"], ws["pad_out"])
-            dist.all_gather_into_tensor(ws["all_st"], ws["pad_st"])
-            ws["rows"].index_copy_(0, ws["dst"], ws["all_out"].index_select(0, ws["src"]))
-            ws["st"].index_copy_(0, ws["dst"], ws["all_st"].index_select(0, ws["src"]))
-            return ws["rows"], ws["st"]    # reused by the next call on this device
+            ws["pad"][:n, :3] = out_local
+            ws["pad"][:n, 3] = status_local      # int8 -> float64, exact
+            dist.all_gather_into_tensor(ws["all"], ws["pad"])
+            ws["host"].copy_(ws["all"])           # device -> host: waits for the collective on the current stream
+            block = ws["host"].numpy()
+            ws["rows"].numpy()[ws["dst"]] = block[ws["src"], :3]
+            ws["st"].numpy()[ws["dst"]] = block[ws["src"], 3].astype(np.int8)
+            return ws["rows"], ws["st"]
         return scatter_to_global(self.pair_lists, out_local, status_local, self.n_pairs)
 
 

@@ -128,12 +128,15 @@ class TiffFile:
                 seen.add(offset)
                 if offset >= size:
                     raise ValueError(f"{self.path}: IFD offset {offset} beyond the end of the file")
-                offset = self._read_ifd(f, bo, big, offset)
+                offset = self._read_ifd(f, bo, big, offset, size)
 
-    def _read_ifd(self, f, bo: str, big: bool, offset: int) -> int:
+    def _read_ifd(self, f, bo: str, big: bool, offset: int, size: int) -> int:
         f.seek(offset)
         n = struct.unpack(bo + ("Q" if big else "H"), f.read(8 if big else 2))[0]
         esz, inline = (20, 8) if big else (12, 4)
+        # the entry count comes from the file: a directory cannot be longer than what is left of the file
+        if offset + (8 if big else 2) + n * esz + (8 if big else 4) > size:
+            raise ValueError(f"{self.path}: IFD at {offset} claims {n} entries, beyond the end of the file")
         raw = f.read(n * esz + (8 if big else 4))
         tags: Dict[int, Tuple[int, int, bytes]] = {}
         for i in range(n):
@@ -149,7 +152,10 @@ class TiffFile:
             typ, count, payload = tags[tag]
             nbytes = _TYPE_SIZE.get(typ, 1) * count
             if nbytes > inline:
-                f.seek(struct.unpack(bo + ("Q" if big else "I"), payload[:inline])[0])
+                at = struct.unpack(bo + ("Q" if big else "I"), payload[:inline])[0]
+                if at + nbytes > size:
+                    raise ValueError(f"{self.path}: tag {tag} points beyond the end of the file")
+                f.seek(at)
                 data = f.read(nbytes)
             else:
                 data = payload[:nbytes]
@@ -221,10 +227,27 @@ class TiffFile:
             return
         if dst.dtype.itemsize != page.bits // 8 or not dst.flags.c_contiguous:
             raise ValueError(f"destination must be C-contiguous with {page.bits // 8}-byte items")
+        # same item size is not the same type: signed or floating-point samples are not copied into unsigned pixels
+        want_kind = {1: "u", 2: "i", 3: "f"}.get(page.sample_format)
+        if want_kind is None or dst.dtype.kind != want_kind:
+            raise ValueError(f"{self.path} page {page_index}: samples of format {page.sample_format} "
+                             f"({page.dtype}) do not go into a {dst.dtype} destination")
         row_bytes = page.width * page.bits // 8
+        # every row has to come from a strip: the destination is uninitialised (or reused) memory
+        n_strips = -(-page.height // page.rows_per_strip) if page.rows_per_strip else 0
+        if len(page.strip_offsets) != n_strips:
+            raise ValueError(f"{self.path} page {page_index}: {len(page.strip_offsets)} strip offsets for {n_strips} strips "
+                             f"({page.height} rows, {page.rows_per_strip} per strip)")
+        counts = page.strip_counts
+        if not counts:
+            # StripByteCounts (tag 279) absent, as old single-strip writers leave it: uncompressed strips hold whole rows
+            counts = [(min(page.height, (k + 1) * page.rows_per_strip) - k * page.rows_per_strip) * row_bytes
+                      for k in range(n_strips)]
+        elif len(counts) != n_strips:
+            raise ValueError(f"{self.path} page {page_index}: {len(counts)} strip byte counts for {n_strips} strips")
         flat = dst.reshape(-1).view(np.uint8)
         with open(self.path, "rb", buffering=0) as f:
-            for s, (off, cnt) in enumerate(zip(page.strip_offsets, page.strip_counts)):
+            for s, (off, cnt) in enumerate(zip(page.strip_offsets, counts)):
                 r0 = s * page.rows_per_strip
                 want = (min(page.height, r0 + page.rows_per_strip) - r0) * row_bytes
                 if cnt < want:

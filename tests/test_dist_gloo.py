@@ -116,12 +116,16 @@ def test_rccl_gather_path_with_a_simulated_collective(monkeypatch):
         local = [(truth[torch.as_tensor(s.pair_ids, dtype=torch.long)], truth_st[torch.as_tensor(s.pair_ids, dtype=torch.long)])
                  for s in shards]
 
+        calls = []
+
         def fake_all_gather(output, inp, _local=local, _pmax=pmax):
-            which = 0 if inp.dtype == torch.float64 else 1
+            assert inp.dtype == torch.float64 and tuple(inp.shape) == (_pmax, 4)   # rows + status, one buffer
+            calls.append(1)
             parts = []
             for r in range(world):
-                pad = torch.full((_pmax, 3), float("nan"), dtype=torch.float64) if which == 0 else torch.ones((_pmax,), dtype=torch.int8)
-                pad[:len(_local[r][which])] = _local[r][which]
+                pad = torch.full((_pmax, 4), float("nan"), dtype=torch.float64)
+                pad[:len(_local[r][0]), :3] = _local[r][0]
+                pad[:len(_local[r][1]), 3] = _local[r][1]
                 parts.append(pad)
             output.copy_(torch.cat(parts))
 
@@ -130,5 +134,7 @@ def test_rccl_gather_path_with_a_simulated_collective(monkeypatch):
         monkeypatch.setattr(tdist, "all_gather_into_tensor", fake_all_gather)
         for r in (0, world - 1):
             for _ in range(2):
+                n_before = len(calls)
                 got, got_st = shards[r].gather(*local[r])
+                assert len(calls) == n_before + 1, "the exchange is ONE collective"
                 assert torch.equal(got, truth) and torch.equal(got_st, truth_st), (world, r)

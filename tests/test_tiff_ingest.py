@@ -53,8 +53,11 @@ def test_eight_bit_and_compressed_pages(tmp_path):
         assert np.array_equal(t.read_page(0), a)       # through Pillow, as the reference falls back to it
 
 
-def _handmade(path, a, big_endian=False, bigtiff=False, strips=3):
-    """A minimal TIFF written field by field: chosen byte order, classic or BigTIFF, several strips."""
+def _handmade(path, a, big_endian=False, bigtiff=False, strips=3, byte_counts=True, drop_last_strip=False,
+              sample_format=None, entry_count=None):
+    """A minimal TIFF written field by field: chosen byte order, classic or BigTIFF, several strips.
+    ``byte_counts=False`` leaves StripByteCounts (tag 279) out, ``drop_last_strip`` lists one strip offset too few,
+    ``sample_format`` adds tag 339, ``entry_count`` overrides the directory's entry count (a corrupt file)."""
     bo = ">" if big_endian else "<"
     h, w = a.shape
     rps = (h + strips - 1) // strips
@@ -86,17 +89,22 @@ def _handmade(path, a, big_endian=False, bigtiff=False, strips=3):
 
     ptr = lambda v: struct.pack(bo + ("Q" if bigtiff else "I"), v)
     one_strip = n_strips == 1
+    listed = n_strips - 1 if drop_last_strip else n_strips
     entries = [entry(256, 4, 1, w), entry(257, 4, 1, h), entry(258, 3, 1, a.itemsize * 8), entry(259, 3, 1, 1),
                entry(262, 3, 1, 1),
-               entry(273, otype, n_strips, offs[0] if one_strip else ptr(offs_at)),
-               entry(277, 3, 1, 1), entry(278, 4, 1, rps),
-               entry(279, otype, n_strips, cnts[0] if one_strip else ptr(cnts_at))]
+               entry(273, otype, listed, offs[0] if listed == 1 else ptr(offs_at)),
+               entry(277, 3, 1, 1), entry(278, 4, 1, rps)]
+    if byte_counts:
+        entries.append(entry(279, otype, listed, cnts[0] if listed == 1 else ptr(cnts_at)))
+    if sample_format is not None:
+        entries.append(entry(339, 3, 1, sample_format))
+    n_entries = len(entries) if entry_count is None else entry_count
     if bigtiff:
         header = (b"MM" if big_endian else b"II") + struct.pack(bo + "HHH", 43, 8, 0) + struct.pack(bo + "Q", ifd_at)
-        ifd = struct.pack(bo + "Q", len(entries)) + b"".join(entries) + struct.pack(bo + "Q", 0)
+        ifd = struct.pack(bo + "Q", n_entries) + b"".join(entries) + struct.pack(bo + "Q", 0)
     else:
         header = (b"MM" if big_endian else b"II") + struct.pack(bo + "H", 42) + struct.pack(bo + "I", ifd_at)
-        ifd = struct.pack(bo + "H", len(entries)) + b"".join(entries) + struct.pack(bo + "I", 0)
+        ifd = struct.pack(bo + "H", n_entries) + b"".join(entries) + struct.pack(bo + "I", 0)
     with open(path, "wb") as f:
         f.write(header + data + arrays + ifd)
 
@@ -113,6 +121,37 @@ def test_byte_orders_and_bigtiff(tmp_path, big_endian, bigtiff, strips):
     if not bigtiff:                                    # Pillow reads classic TIFFs of either byte order: same pixels
         with PIL.open(p) as im:
             assert np.array_equal(np.asarray(im), a)
+
+
+@pytest.mark.parametrize("strips", [1, 3])
+def test_a_file_without_strip_byte_counts_is_read_whole(tmp_path, strips):
+    """Old writers leave StripByteCounts out: the counts follow from the rows of every strip."""
+    a = _img(5, 60, 90)
+    p = str(tmp_path / "C_0_0_x.tiff")
+    _handmade(p, a, strips=strips, byte_counts=False)
+    t = tiff.TiffFile(p)
+    assert t.pages[0].strip_counts == []
+    dst = np.full((60, 90), 0xABCD, dtype=np.uint16)      # stale contents of a reused staging buffer
+    t.read_page_into(0, dst)
+    assert np.array_equal(dst, a)
+
+
+def test_pages_that_cannot_fill_the_destination_are_refused(tmp_path):
+    a = _img(6, 60, 90)
+    p = str(tmp_path / "D_0_0_x.tiff")
+    _handmade(p, a, strips=3, drop_last_strip=True)        # a strip is missing: part of the page would stay stale
+    with pytest.raises(ValueError, match="strip"):
+        tiff.TiffFile(p).read_page_into(0, np.zeros((60, 90), dtype=np.uint16))
+    for fmt, dtype in ((2, np.int16), (3, np.float16)):    # signed / floating-point samples of the same item size
+        _handmade(p, a.view(dtype), strips=2, sample_format=fmt)
+        t = tiff.TiffFile(p)
+        with pytest.raises(ValueError, match="format"):
+            t.read_page_into(0, np.zeros((60, 90), dtype=np.uint16))
+        assert t.read_page(0).dtype == np.dtype(dtype)     # into a buffer of its own type it still reads
+    for big in (False, True):                              # an entry count far beyond the file
+        _handmade(p, a, bigtiff=big, entry_count=60000 if not big else 1 << 40)
+        with pytest.raises(ValueError, match="entries"):
+            tiff.TiffFile(p)
 
 
 def test_stack_files_give_their_middle_page(tmp_path):
