@@ -552,65 +552,108 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
   // against those few without touching pixel memory (0: uncovered, 1: plain copy from
   // one tile, 2: queued, 3: outside the mosaic), issues all copy loads back to back
   // and stores.
-  for (int y = y0 + wave; y < y1; y += kFuseThreads / 64) {
+  //
+  // The classification of a row depends on the row only through (a) the alignment of its first pixel (its address
+  // modulo 16 bytes, which repeats every 8 rows whatever the mosaic's width), (b) the set of tiles whose rows
+  // include it and (c) whether it is the first or last row of one of them.  A wave therefore takes its rows in the
+  // order 0, 8, 16, 24, 4, 12, 20, 28 (+ its number): consecutive rows share (a), and away from the tiles' first
+  // and last rows (b) and (c) too, so that the classification of the previous row stands and only addresses,
+  // loads and stores remain (vector instructions issue on 59 % of this kernel's cycles: they, not memory, set its pace).
+  constexpr int kWaves = kFuseThreads / 64;
+  constexpr int kRowsPerWave = (kBH + kWaves - 1) / kWaves;
+  unsigned kinds = 0;        // two bits per group
+  unsigned csel = 0;         // 5 bits per group: the list entry a plain copy reads
+  unsigned qinfo[GX];        // queue entry of the group less its row
+  unsigned qbatched = 0;     // bit r: the entry goes to the batched blends
+  int prev_a = -1;
+  unsigned prev_ymask = 0, prev_edges = 1;  // no previous row yet
+#pragma unroll
+  for (int r = 0; r < GX; ++r) qinfo[r] = 0;
+  for (int it = 0; it < kRowsPerWave; ++it) {
+    const int half = (kRowsPerWave + 1) / 2;
+    const int kk = it < half ? 2 * it : 2 * (it - half) + 1;  // even steps first, then the odd ones
+    const int y = y0 + wave + kk * kWaves;
+    if (y >= y1) continue;  // wave-uniform
     uint16_t* rowp = mplane + (int64_t)y * Wm;
     const int a = (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
     const int64_t yW = (int64_t)y * W;
-    unsigned ymask = 0;
+    unsigned ymask = 0, edges = 0;
     if (!generic_only) {
-      const bool in_rows = lane < ncand && (unsigned)(y - list[lane & (kMaxCand - 1)].ty) < (unsigned)H;
+      const int ly_mine = y - list[lane & (kMaxCand - 1)].ty;
+      const bool in_rows = lane < ncand && (unsigned)ly_mine < (unsigned)H;
       ymask = (unsigned)__ballot(in_rows);
+      edges = (unsigned)__ballot(in_rows && ((ly_mine == 0) | (ly_mine == H - 1)));
     }
     const int x0 = 8 * w_idx - a;
-    int cnt[GX];
-    unsigned idx[GX];    // touching candidates, 5 bits each, the last placed in the lowest bits
-    bool bad[GX];        // some touching tile covers the group only partly or lacks a flatfield plane
-    bool last_bad[GX];   // the same for the last placed touching tile alone
-    bool hard[GX];       // a touching tile that no batched blend or selection can take (see blend_group)
-    bool full[GX];       // some touching tile covers all 8 pixels
-#pragma unroll
-    for (int r = 0; r < GX; ++r) {
-      cnt[r] = 0;
-      idx[r] = 0;
-      bad[r] = last_bad[r] = hard[r] = full[r] = false;
-    }
-    for (unsigned m = ymask; m; m &= m - 1u) {  // wave-uniform loop over the row's tiles
-      const int ci = __builtin_ctz(m);
-      const int tx = list[ci].tx;
-      const bool not_ok = !((ffok >> ci) & 1u);
-      const int ly = y - list[ci].ty;
-      const bool edge_row = (ly == 0) | (ly == H - 1);  // a partly covering tile's load would leave the tile here
+    if (!(a == prev_a && ymask == prev_ymask && (edges | prev_edges) == 0)) {  // wave-uniform
+      int cnt[GX];
+      unsigned idx[GX];    // touching candidates, 5 bits each, the last placed in the lowest bits
+      bool bad[GX];        // some touching tile covers the group only partly or lacks a flatfield plane
+      bool last_bad[GX];   // the same for the last placed touching tile alone
+      bool hard[GX];       // a touching tile that no batched blend or selection can take (see blend_group)
+      bool full[GX];       // some touching tile covers all 8 pixels
 #pragma unroll
       for (int r = 0; r < GX; ++r) {
-        const int lx0 = x0 + 512 * r - tx;
-        const bool touch = (unsigned)(lx0 + 7) < (unsigned)(W + 7);
-        const bool cut = (unsigned)lx0 > (unsigned)(W - 8);
-        const bool part = cut | not_ok;
-        idx[r] = touch ? ((idx[r] << 5) | (unsigned)ci) : idx[r];
-        cnt[r] += touch ? 1 : 0;
-        bad[r] = bad[r] | (touch & part);
-        last_bad[r] = touch ? part : last_bad[r];
-        hard[r] = hard[r] | (touch & (not_ok | (cut & edge_row)));
-        full[r] = full[r] | (touch & !cut);
+        cnt[r] = 0;
+        idx[r] = 0;
+        bad[r] = last_bad[r] = hard[r] = full[r] = false;
+      }
+      for (unsigned m = ymask; m; m &= m - 1u) {  // wave-uniform loop over the row's tiles
+        const int ci = __builtin_ctz(m);
+        const int tx = list[ci].tx;
+        const bool not_ok = !((ffok >> ci) & 1u);
+        const bool edge_row = (edges >> ci) & 1u;  // a partly covering tile's load would leave the tile here
+#pragma unroll
+        for (int r = 0; r < GX; ++r) {
+          const int lx0 = x0 + 512 * r - tx;
+          const bool touch = (unsigned)(lx0 + 7) < (unsigned)(W + 7);
+          const bool cut = (unsigned)lx0 > (unsigned)(W - 8);
+          const bool part = cut | not_ok;
+          idx[r] = touch ? ((idx[r] << 5) | (unsigned)ci) : idx[r];
+          cnt[r] += touch ? 1 : 0;
+          bad[r] = bad[r] | (touch & part);
+          last_bad[r] = touch ? part : last_bad[r];
+          hard[r] = hard[r] | (touch & (not_ok | (cut & edge_row)));
+          full[r] = full[r] | (touch & !cut);
+        }
+      }
+      kinds = csel = qbatched = 0;
+#pragma unroll
+      for (int r = 0; r < GX; ++r) {
+        const int x = x0 + 512 * r;
+        const bool outside = !((unsigned)(x + 7) < (unsigned)(Wm + 7));
+        const bool inside = (unsigned)x <= (unsigned)(Wm - 8);  // not cut by the mosaic edge
+        const bool copy = MODE == MISTITCH_FUSE_OVERWRITE ? !last_bad[r] : (cnt[r] == 1) & !bad[r];
+        int k = (cnt[r] == 0) ? 0 : (copy ? 1 : 2);
+        k = (!inside | generic_only) ? 2 : k;
+        k = outside ? 3 : k;
+        kinds |= (unsigned)k << (2 * r);
+        csel |= (idx[r] & 31u) << (5 * r);
+        // the queue entry of a group that is not a plain copy: two sources may have any list index; three or four
+        // must all lie below 16 (4-bit fields)
+        const unsigned i5 = idx[r];
+        const bool small = ((i5 | (i5 >> 5) | (i5 >> 10) | (i5 >> 15)) & 16u) == 0;
+        const bool batched = !generic_only && inside && !hard[r] && (cnt[r] <= 2 || (cnt[r] <= 4 && small)) &&
+                             (MODE == MISTITCH_FUSE_FEATHER ? (full[r] && cnt[r] >= 2) : cnt[r] >= 1);
+        const unsigned packed = cnt[r] <= 2 ? (i5 & 0x3ffu)
+                                            : ((i5 & 15u) | ((i5 >> 1) & 0xf0u) | ((i5 >> 2) & 0xf00u) | ((i5 >> 3) & 0xf000u));
+        qinfo[r] = (unsigned)(lane + 64 * r) | (batched ? ((unsigned)(cnt[r] - 1) << 13) | (packed << 15) : 0u);
+        qbatched |= (batched ? 1u : 0u) << r;
       }
     }
+    prev_a = a;
+    prev_ymask = ymask;
+    prev_edges = edges;
     Px8 v[GX];
     F8 f32[FF == MISTITCH_FF_F32 ? GX : 1];
     D8 f64[FF == MISTITCH_FF_F64 ? GX : 1];
-    unsigned kinds = 0;  // two bits per group
 #pragma unroll
     for (int r = 0; r < GX; ++r) {
       const int x = x0 + 512 * r;
-      const bool outside = !((unsigned)(x + 7) < (unsigned)(Wm + 7));
-      const bool inside = (unsigned)x <= (unsigned)(Wm - 8);  // not cut by the mosaic edge
-      const bool copy = MODE == MISTITCH_FUSE_OVERWRITE ? !last_bad[r] : (cnt[r] == 1) & !bad[r];
-      int k = (cnt[r] == 0) ? 0 : (copy ? 1 : 2);
-      k = (!inside | generic_only) ? 2 : k;
-      k = outside ? 3 : k;
-      kinds |= (unsigned)k << (2 * r);
+      const unsigned k = (kinds >> (2 * r)) & 3u;
       // copy loads never sit behind a branch: lanes without a plain copy read tile 0's first pixels (idle_off = 0;
       // the host points both idle offsets at the workspace when the tile or flatfield array holds fewer than 8 values)
-      const TileRef* c = list + (idx[r] & 31u);
+      const TileRef* c = list + ((csel >> (5 * r)) & 31u);
       const int64_t at = yW + x;
       const int64_t off = k == 1 ? c->src_base + at : idle_off;
       const int64_t foff = k == 1 ? c->ff_base + at : idle_foff;
@@ -641,21 +684,11 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
       } else if (k == 2) {
         // queued for the whole workgroup: these groups cluster in the overlap bands, and
         // handled in place they would stall every wave that owns a few
-        unsigned e = (unsigned)(lane + 64 * r) | ((unsigned)(y - y0) << 8);
-        const bool inside = (unsigned)x <= (unsigned)(Wm - 8);
-        // two sources may have any list index; three or four must all lie below 16 (4-bit fields)
-        const unsigned i5 = idx[r];
-        const bool small = ((i5 | (i5 >> 5) | (i5 >> 10) | (i5 >> 15)) & 16u) == 0;
-        const bool batched = !generic_only && inside && !hard[r] && (cnt[r] <= 2 || (cnt[r] <= 4 && small)) &&
-                             (MODE == MISTITCH_FUSE_FEATHER ? (full[r] && cnt[r] >= 2) : cnt[r] >= 1);
-        if (batched) {
-          const unsigned packed = cnt[r] <= 2 ? (i5 & 0x3ffu)
-                                              : ((i5 & 15u) | ((i5 >> 1) & 0xf0u) | ((i5 >> 2) & 0xf00u) | ((i5 >> 3) & 0xf000u));
-          e |= ((unsigned)(cnt[r] - 1) << 13) | (packed << 15);
+        const unsigned e = qinfo[r] | ((unsigned)(y - y0) << 8);
+        if ((qbatched >> r) & 1u)
           queue[atomicAdd(&queue_len[0], 1u)] = e;
-        } else {
+        else
           queue[kQueue - 1 - atomicAdd(&queue_len[1], 1u)] = e;
-        }
       }
     }
   }
