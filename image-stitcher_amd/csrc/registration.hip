@@ -931,39 +931,53 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
 }
 
 // The column pass for complex128 columns of S = 128 or 256 rows with every radix pass in registers (the scheme of
-// fft_reg.hpp along the short axis).  A unit is 8 stored columns and the 8 columns of their negated frequencies:
-// lanes [0, S) take the stored columns, lanes [S, 2S) the others, lane (c, q) = (lane & 7, lane / 8) holding 8 rows of
-// column c.  In memory a unit's 8 columns are ONE contiguous [S][8] block of the slab buffer, so a wave's loads cover
-// 8 whole rows (1 KiB).  The passes (S / 64, 8, 8) exchange through LDS (row r of a half at slot r + r / 8, rows of
-// 128 bytes: conflict free for the row sets of every pass); the forward transform's last pass leaves a lane the 8
-// storage positions that the inverse transform's first pass starts from, so the cross-power stage works on registers
-// and only reads the partner cells from LDS.  The second half's waves leave once their transform is published.
-// grid (n_units, pairs_in_pass), 2 S lanes.
-template <int S>
-__global__ __launch_bounds__(2 * S, 4) void k_fft_short_cps_reg(const PairDesc* desc, const int8_t* status, int pair0, int L,
-                                                             int want_transposed, const double2* __restrict__ roots,
-                                                             const uint16_t* __restrict__ mpos_s,
-                                                             const uint16_t* __restrict__ pos2freq_s,
-                                                             const uint16_t* __restrict__ mpos_l,
-                                                             const CpsUnit* __restrict__ units, const double2* slabs,
-                                                             double2* spectrum, double eps, double2* keep_r,
-                                                             const uint16_t* __restrict__ pos2stored, int n_stored) {
+// fft_reg.hpp along the short axis).  A workgroup takes NC stored columns and the NC columns of their negated
+// frequencies: lanes [0, NC S / 8) take the stored columns, the rest the others, lane (c, q) = (lane % NC, lane / NC)
+// holding 8 rows of column c.  In memory the 8 columns of a unit are ONE contiguous [S][8] block of the slab buffer,
+// so a wave's loads cover whole rows (NC = 8) or half rows (NC = 4).  The passes (S / 64, 8, 8) exchange through LDS
+// (row r of a half at slot r + r / 8: conflict free for the row sets of every pass); the forward transform's last
+// pass leaves a lane the 8 storage positions that the inverse transform's first pass starts from, so the cross-power
+// stage works on registers and only reads the partner cells from LDS.  The second half's waves leave once their
+// transform is published.
+// NC = 8: one unit per workgroup, and the units whose stored columns hold their own negated frequencies (nb = 0:
+// the second half repeats the first).  NC = 4: HALF a paired unit per workgroup - the mirror of stored column c of a
+// unit is column 7 - c of its partner block, so columns 0-3 go with the partner's 4-7 and the reverse; four
+// workgroups of 256 lanes share a CU instead of two of 512; the two halves of a unit, which share every 128-byte row
+// of its slabs, are dealt to the same XCD (grid.x a multiple of 16: block x -> unit (x / 16) 8 + x % 8, half x / 8 % 2).
+// Measured 2 % SLOWER than whole units on the 2048 x 256 strips (2.37 against 2.32 ms per 760 pairs), so it only runs
+// when MISTITCH_CPS_HALF_UNITS is set in the environment (an experiment switch).
+// grid (n_units or 16 ceil(n_units / 8), pairs_in_pass), 2 NC S / 8 lanes.
+template <int S, int NC>
+__global__ __launch_bounds__(2 * NC * S / 8, NC == 8 ? 4 : 4) void k_fft_short_cps_reg(
+    const PairDesc* desc, const int8_t* status, int pair0, int L, int want_transposed, const double2* __restrict__ roots,
+    const uint16_t* __restrict__ mpos_s, const uint16_t* __restrict__ pos2freq_s, const uint16_t* __restrict__ mpos_l,
+    const CpsUnit* __restrict__ units, int n_units, const double2* slabs, double2* spectrum, double eps, double2* keep_r,
+    const uint16_t* __restrict__ pos2stored, int n_stored) {
   constexpr int Q = S / 8;            // lanes per column
   constexpr int R0 = S / 64;          // radix of the first pass
   constexpr int NB = 8 / R0;          // its butterflies per lane
   constexpr int kRows = S + S / 8;    // slots of a half
-  static_assert(S == 128 || S == 256, "passes (S / 64, 8, 8)");
+  constexpr int kHalfLanes = NC * Q;
+  static_assert((S == 128 || S == 256) && (NC == 4 || NC == 8) && kHalfLanes % 64 == 0, "passes (S / 64, 8, 8), whole waves per half");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double2* buf = reinterpret_cast<double2*>(smem_raw);
   const int p = pair0 + blockIdx.y;
   const int8_t pair_status = status[p];
   const int d_S = desc[p].S, d_L = desc[p].L, d_transposed = desc[p].transposed;
-  const CpsUnit un = units[blockIdx.x];
+  int ui = blockIdx.x, hh = 0;
+  if constexpr (NC == 4) {
+    ui = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7);
+    hh = ((int)blockIdx.x >> 3) & 1;
+  }
+  if (ui >= n_units) return;
+  const CpsUnit un = units[ui];
   const int tid = threadIdx.x;
-  const int half = tid >= S ? 1 : 0, lt = tid - half * S;
-  const int c = lt & 7, q = lt >> 3;
-  const bool single = un.nb == 0;  // the stored columns hold their own negated frequencies: the second half repeats them
-  const int pos = (half == 0 || single ? un.a0 : un.b0) + c;
+  const int half = tid >= kHalfLanes ? 1 : 0, lt = tid - half * kHalfLanes;
+  const int c = lt & (NC - 1), q = lt / NC;
+  const bool single = NC == 8 && un.nb == 0;  // the stored columns hold their own negated frequencies: the second half repeats them
+  const int a_base = un.a0 + (NC == 4 ? 4 * hh : 0);
+  const int b_base = single ? a_base : un.b0 + (NC == 4 ? 4 * (1 - hh) : 0);
+  const int pos = (half == 0 ? a_base : b_base) + c;
   const int64_t sp = slab_pitch(S);
   const double2* src = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L) + (pos / kSlab) * sp + pos % kSlab;
   double2 v[8];
@@ -973,12 +987,12 @@ __global__ __launch_bounds__(2 * S, 4) void k_fft_short_cps_reg(const PairDesc* 
 #pragma unroll
   for (int k = 0; k < NB; ++k) tw0[k] = roots[q + k * Q];
   const double2 tw1 = roots[(q & 7) * (S / 64)];
-  const int mp = mpos_l[un.a0 + c];
+  const int mp = mpos_l[a_base + c];
   const uint4 mrow4 = *reinterpret_cast<const uint4*>(mpos_s + 8 * q);       // partner rows of rows 8 q .. 8 q + 7
-  const int col0 = pos2stored[un.a0];
+  const int col0 = pos2stored[a_base];
   if (pair_status != MISTITCH_PAIR_OK) return;
   if (d_S != S || d_L != L || (want_transposed >= 0 && d_transposed != want_transposed)) return;
-  double2* mine = buf + half * (kRows * 8);
+  double2* mine = buf + half * (kRows * NC);
   // first pass: rows q + Q j
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
@@ -990,34 +1004,34 @@ __global__ __launch_bounds__(2 * S, 4) void k_fft_short_cps_reg(const PairDesc* 
     for (int m = 0; m < R0; ++m) v[k + NB * m] = x[m];
   }
   auto slot = [](int r) { return r + (r >> 3); };
-  double2* at_a = mine + slot(q) * 8 + c;                          // rows q + Q j
-  double2* at_b = mine + slot((q >> 3) * 64 + (q & 7)) * 8 + c;    // rows (q / 8) 64 + q % 8 + 8 m
-  double2* at_c = mine + 9 * q * 8 + c;                            // rows 8 q + m
+  double2* at_a = mine + slot(q) * NC + c;                          // rows q + Q j
+  double2* at_b = mine + slot((q >> 3) * 64 + (q & 7)) * NC + c;    // rows (q / 8) 64 + q % 8 + 8 m
+  double2* at_c = mine + 9 * q * NC + c;                            // rows 8 q + m
 #pragma unroll
-  for (int j = 0; j < 8; ++j) at_a[j * (Q + Q / 8) * 8] = v[j];
+  for (int j = 0; j < 8; ++j) at_a[j * (Q + Q / 8) * NC] = v[j];
   lds_barrier();
 #pragma unroll
-  for (int m = 0; m < 8; ++m) v[m] = at_b[9 * m * 8];
+  for (int m = 0; m < 8; ++m) v[m] = at_b[9 * m * NC];
   RegFft<512>::butterfly<8, false>(v, tw1, true);
 #pragma unroll
-  for (int m = 0; m < 8; ++m) at_b[9 * m * 8] = v[m];  // in place: the slots this lane has just read
+  for (int m = 0; m < 8; ++m) at_b[9 * m * NC] = v[m];  // in place: the slots this lane has just read
   lds_barrier();
 #pragma unroll
-  for (int m = 0; m < 8; ++m) v[m] = at_c[m * 8];
+  for (int m = 0; m < 8; ++m) v[m] = at_c[m * NC];
   RegFft<512>::butterfly<8, false>(v, mk<double>(1.0, 0.0), false);
 #pragma unroll
-  for (int m = 0; m < 8; ++m) at_c[m * 8] = v[m];
+  for (int m = 0; m < 8; ++m) at_c[m * NC] = v[m];
   lds_barrier();
   if (half == 1) return;  // whole waves: the barriers below count the surviving ones
   // normalised cross-power spectrum of the two strips packed in z = A + i B (see k_fft_short_cps)
-  const double2* partner = buf + (single ? 0 : kRows * 8) + (single ? mp - un.a0 : mp - un.b0);
+  const double2* partner = buf + (single ? 0 : kRows * NC) + (mp - b_base);
   const unsigned mrow[8] = {mrow4.x & 0xffffu, mrow4.x >> 16, mrow4.y & 0xffffu, mrow4.y >> 16,
                             mrow4.z & 0xffffu, mrow4.z >> 16, mrow4.w & 0xffffu, mrow4.w >> 16};
 #pragma unroll
   for (int h = 0; h < 8; h += 4) {  // four cells at a time: their partner reads in flight together
     double2 zm[4];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) zm[m] = partner[slot((int)mrow[h + m]) * 8];
+    for (int m = 0; m < 4; ++m) zm[m] = partner[slot((int)mrow[h + m]) * NC];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const double2 z = v[h + m];
@@ -1042,16 +1056,16 @@ __global__ __launch_bounds__(2 * S, 4) void k_fft_short_cps_reg(const PairDesc* 
   RegFft<512>::butterfly<8, true>(v, mk<double>(1.0, 0.0), false);
   if (single) lds_barrier();  // the partner cells lie in this half: every lane has to have read them (workgroup uniform)
 #pragma unroll
-  for (int m = 0; m < 8; ++m) at_c[m * 8] = v[m];
+  for (int m = 0; m < 8; ++m) at_c[m * NC] = v[m];
   lds_barrier();
 #pragma unroll
-  for (int m = 0; m < 8; ++m) v[m] = at_b[9 * m * 8];
+  for (int m = 0; m < 8; ++m) v[m] = at_b[9 * m * NC];
   RegFft<512>::butterfly<8, true>(v, tw1, true);
 #pragma unroll
-  for (int m = 0; m < 8; ++m) at_b[9 * m * 8] = v[m];  // in place
+  for (int m = 0; m < 8; ++m) at_b[9 * m * NC] = v[m];  // in place
   lds_barrier();
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = at_a[j * (Q + Q / 8) * 8];
+  for (int j = 0; j < 8; ++j) v[j] = at_a[j * (Q + Q / 8) * NC];
 #pragma unroll
   for (int k = 0; k < NB; ++k) {
     double2 x[R0];
@@ -1061,7 +1075,7 @@ __global__ __launch_bounds__(2 * S, 4) void k_fft_short_cps_reg(const PairDesc* 
 #pragma unroll
     for (int m = 0; m < R0; ++m) v[k + NB * m] = x[m];
   }
-  // natural order out: rows q + Q j of the packed intermediate spectrum, 8 columns = 128 bytes per row
+  // natural order out: rows q + Q j of the packed intermediate spectrum, NC columns (128 or 64 bytes) per row
   const int Lp = spectrum_pitch<double>(n_stored);
   double2* Z = spectrum + (int64_t)blockIdx.y * S * Lp + col0 + c;
 #pragma unroll
@@ -3095,6 +3109,9 @@ struct ShapeCfg {
   FftPlanDev planS, planL;
   int C;       // columns per block of the column pass (LDS rows hold 2C)
   bool reg_cols;  // every unit is 8 stored columns, alone or with the 8 of their negated frequencies (k_fft_short_cps_reg)
+  const CpsUnit* units_paired;  // device: the units with a partner block, and those without (their own mirrors)
+  const CpsUnit* units_single;
+  int n_paired, n_single;
   const CpsUnit* units;    // device
   int n_units;
   const uint16_t* stored_pos;   // device: positions k_fft_short_cps wrote, ascending
@@ -3210,10 +3227,23 @@ static int make_shape(mistitch_ctx* ctx, int S, int L, bool f64, ShapeCfg* cfg) 
         if (has[i]) ups_slabs.push_back((uint16_t)(i * kSlab));
     }
     void* blob = nullptr;
-    MS_HIP(hipMalloc(&blob, ub_pad + 2 * sb_pad + pb + kb + 3 * sb_pad + 64));
+    MS_HIP(hipMalloc(&blob, ub_pad + 2 * sb_pad + pb + kb + 3 * sb_pad + 64 + ub_pad + 16));
     ctx->shape_allocs.push_back(blob);
     char* base = reinterpret_cast<char*>(blob);
     MS_HIP(hipMemcpy(base, units.data(), ub, hipMemcpyHostToDevice));
+    {
+      // the same units, those with a partner block first (k_fft_short_cps_reg takes the two kinds in separate launches)
+      std::vector<CpsUnit> sorted_units;
+      for (const CpsUnit& u : units) if (u.nb != 0) sorted_units.push_back(u);
+      cfg->n_paired = (int)sorted_units.size();
+      for (const CpsUnit& u : units) if (u.nb == 0) sorted_units.push_back(u);
+      cfg->n_single = (int)sorted_units.size() - cfg->n_paired;
+      char* at = base + ub_pad + 2 * sb_pad + pb + kb + 3 * sb_pad + 64;
+      at = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(at) + 15) & ~(uintptr_t)15);
+      MS_HIP(hipMemcpy(at, sorted_units.data(), ub, hipMemcpyHostToDevice));
+      cfg->units_paired = reinterpret_cast<const CpsUnit*>(at);
+      cfg->units_single = cfg->units_paired + cfg->n_paired;
+    }
     MS_HIP(hipMemcpy(base + ub_pad, stored_pos.data(), sb, hipMemcpyHostToDevice));
     MS_HIP(hipMemcpy(base + ub_pad + sb_pad, mirror_fill.data(), sb, hipMemcpyHostToDevice));
     MS_HIP(hipMemcpy(base + ub_pad + 2 * sb_pad, pos2stored.data(), (size_t)L * 2, hipMemcpyHostToDevice));
@@ -3714,11 +3744,26 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
       const double2* roots = reinterpret_cast<const double2*>(cfg.planS.tw);
 #define MS_CPS_REG(SS)                                                                                                 \
   do {                                                                                                                 \
-    const size_t lds = (size_t)2 * (SS + SS / 8) * 8 * sizeof(double2);                                                \
-    if ((rc = allow_lds(ctx, k_fft_short_cps_reg<SS>, lds))) return rc;                                                \
-    MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps_reg<SS>), dim3(cfg.n_units, n), dim3(2 * SS), lds, ws.desc, status, \
-              pair0, cfg.L, want_transposed, roots, cfg.planS.mpos, cfg.planS.pos2freq, cfg.planL.mpos, cfg.units, slabs, \
-              spec, (double)eps, ws.n_up ? slabs : (double2*)nullptr, cfg.pos2stored, cfg.n_stored);                    \
+    const size_t lds8 = (size_t)2 * (SS + SS / 8) * 8 * sizeof(double2), lds4 = lds8 / 2;                               \
+    double2* keep = ws.n_up ? slabs : (double2*)nullptr;                                                               \
+    if ((rc = allow_lds(ctx, k_fft_short_cps_reg<SS, 8>, lds8))) return rc;                                            \
+    if (!getenv("MISTITCH_CPS_HALF_UNITS")) {  /* whole units by default: halves measured 2 % slower */                                                                          \
+      MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps_reg<SS, 8>), dim3(cfg.n_units, n), dim3(2 * SS), lds8, ws.desc, \
+                status, pair0, cfg.L, want_transposed, roots, cfg.planS.mpos, cfg.planS.pos2freq, cfg.planL.mpos,       \
+                cfg.units, cfg.n_units, slabs, spec, (double)eps, keep, cfg.pos2stored, cfg.n_stored);                  \
+    } else {                                                                                                           \
+      if ((rc = allow_lds(ctx, k_fft_short_cps_reg<SS, 4>, lds4))) return rc;                                          \
+      if (cfg.n_paired > 0)                                                                                            \
+        MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps_reg<SS, 4>), dim3(16 * ((cfg.n_paired + 7) / 8), n), dim3(SS), \
+                  lds4, ws.desc, status, pair0, cfg.L, want_transposed, roots, cfg.planS.mpos, cfg.planS.pos2freq,     \
+                  cfg.planL.mpos, cfg.units_paired, cfg.n_paired, slabs, spec, (double)eps, keep, cfg.pos2stored,      \
+                  cfg.n_stored);                                                                                       \
+      if (cfg.n_single > 0)                                                                                            \
+        MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps_reg<SS, 8>), dim3(cfg.n_single, n), dim3(2 * SS), lds8,     \
+                  ws.desc, status, pair0, cfg.L, want_transposed, roots, cfg.planS.mpos, cfg.planS.pos2freq,           \
+                  cfg.planL.mpos, cfg.units_single, cfg.n_single, slabs, spec, (double)eps, keep, cfg.pos2stored,      \
+                  cfg.n_stored);                                                                                       \
+    }                                                                                                                  \
   } while (0)
       if (cfg.S == 128) MS_CPS_REG(128);
       else MS_CPS_REG(256);
