@@ -2585,17 +2585,19 @@ __device__ __forceinline__ void reduce_moments(unsigned long long (&v)[5], unsig
 // on one XCD, whose L2 keeps that pair's two strips while its ~30 overlaps are read from them.
 constexpr int kXcds = 8;
 constexpr int kShortStripRows = 256;  // the usual edge width: sizes the "small overlap" test below
+// Candidates [ci0, ci0 + n_ci) of every pair are summed: all n_cand + 1 of them, or the subpixel slot alone when
+// k_ncc_sweep has taken the signed interpretations of the peaks.
 __global__ __launch_bounds__(kThreads, 8) void k_ncc_accumulate(const PairDesc* desc, const int8_t* status,
                                                              int pair0, int n_in_pass, const Cand* cand,
-                                                             unsigned long long* acc, int n_cand) {
+                                                             unsigned long long* acc, int n_cand, int ci0, int n_ci) {
   __shared__ unsigned long long red[5 * kThreads / 64];
   const int xcd = blockIdx.x % kXcds, seq = blockIdx.x / kXcds;
   const int slots = n_cand + 1;
-  const int kPerPair = kNccChunks * slots;
+  const int kPerPair = kNccChunks * n_ci;
   const int pz = xcd + kXcds * (seq / kPerPair);
   if (pz >= n_in_pass) return;
   const int within = seq % kPerPair;
-  const int ci = within / kNccChunks, chunk = within % kNccChunks;
+  const int ci = ci0 + within / kNccChunks, chunk = within % kNccChunks;
   const int p = pair0 + pz;
   // three independent lookups, requested together ahead of the first test
   const int8_t st = status[p];
@@ -2619,6 +2621,280 @@ __global__ __launch_bounds__(kThreads, 8) void k_ncc_accumulate(const PairDesc* 
   moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl), d.pitch, first, s_hi, step,
                   l_hi - l_lo, v);
   reduce_moments(v, red, acc + ((int64_t)p * slots + ci) * 5);
+}
+
+// ---- candidate moments by circular sweeps ----------------------------------------
+// The 16 signed interpretations of a peak (n rows, m columns in canonical orientation) are the shifts
+// (+-n | +-(S - n), +-m | +-(L - m)).  Shifts +n and -(S - n) pair row r of the first strip with row (r - n) mod S of
+// the second: the rows r >= n belong to the former, the rows r < n to the latter, and together they are every row
+// once.  The same holds along a row for +m and -(L - m), and for the opposite lags.  So four circular sweeps of the
+// strip pair (row lag +-n, column lag +-m) visit every pixel pair of all 16 overlaps exactly once, where 16 separate
+// windows read four strip areas of either strip.  A workgroup takes up to kSweepRows rows of one row lag on one side of
+// the wrap, loads a row of the first strip ONCE (16 bytes per lane, aligned) and the paired row of the second strip at
+// the two column lags, and keeps the byte-plane sums of both lags: the moments of the first strip are formed once, not
+// once per candidate.  Every lane owns one 8-pixel group of the row, which lies on one side of a lag's wrap column for
+// all rows, so its sums go to one candidate per lag.  The one group that a lag's wrap column cuts is left out of that
+// lag's sums and taken pixel by pixel afterwards, wave w for (lag w / 2, side w % 2).
+// Byte-plane sums are reduced over the 16 lanes of a DPP row in 32 bits and added to the workgroup's 64-bit planes in
+// LDS; 20 threads turn the planes into moments and add them to the candidates' accumulators.
+// grid: 8 * ceil(pairs_in_pass / 8) * n_peaks * 2 * n_row_chunks * n_col_chunks workgroups, a pair's on one XCD as in
+// k_ncc_accumulate.  Rows are 16-byte aligned and L is a multiple of 8 (the host checks).
+#ifndef MS_SWEEP_ROWS
+#define MS_SWEEP_ROWS 32
+#endif
+#ifndef MS_SWEEP_OCC
+#define MS_SWEEP_OCC 6
+#endif
+constexpr int kSweepRows = MS_SWEEP_ROWS;
+// a lane calls add4 twice per row; the busiest byte plane gains at most 520,200 per call, and the sum of a plane over
+// the 16 lanes of a DPP row has to fit 32 bits (row_sum)
+static_assert(2ll * kSweepRows * 520200ll * 16ll < (1ll << 32), "byte-plane sums of 16 lanes overflow 32 bits");
+constexpr int kPlanes = 13;  // a_l a_h b_l b_h aa_ll aa_lh aa_hh bb_ll bb_lh bb_hh ab_ll ab_x ab_hh
+
+// Sum of v over each 16 consecutive lanes, valid in every lane of the 16.
+__device__ __forceinline__ unsigned row_sum(unsigned v) {
+  v += dpp_u32<kDppXor1>(v);
+  v += dpp_u32<kDppXor2>(v);
+  v += dpp_u32<kDppHalfMirror>(v);
+  v += dpp_u32<kDppMirror>(v);
+  return v;
+}
+
+struct SweepAcc {
+  unsigned a_l = 0, a_h = 0, aa_ll = 0, aa_lh = 0, aa_hh = 0;  // first strip: shared by both lags
+  unsigned b_l[2] = {0, 0}, b_h[2] = {0, 0}, bb_ll[2] = {0, 0}, bb_lh[2] = {0, 0}, bb_hh[2] = {0, 0};
+  unsigned ab_ll[2] = {0, 0}, ab_x[2] = {0, 0}, ab_hh[2] = {0, 0};
+  template <bool LA, bool LB>
+  __device__ __forceinline__ void add4(unsigned a0, unsigned a1, unsigned x0, unsigned x1, unsigned y0, unsigned y1) {
+    const unsigned al = __builtin_amdgcn_perm(a1, a0, 0x06040200u), ah = __builtin_amdgcn_perm(a1, a0, 0x07050301u);
+    a_l = __builtin_amdgcn_udot4(al, 0x01010101u, a_l, false);
+    a_h = __builtin_amdgcn_udot4(ah, 0x01010101u, a_h, false);
+    aa_ll = __builtin_amdgcn_udot4(al, al, aa_ll, false);
+    aa_lh = __builtin_amdgcn_udot4(al, ah, aa_lh, false);
+    aa_hh = __builtin_amdgcn_udot4(ah, ah, aa_hh, false);
+    auto lag = [&](int k, unsigned b0, unsigned b1) {
+      const unsigned bl = __builtin_amdgcn_perm(b1, b0, 0x06040200u), bh = __builtin_amdgcn_perm(b1, b0, 0x07050301u);
+      b_l[k] = __builtin_amdgcn_udot4(bl, 0x01010101u, b_l[k], false);
+      b_h[k] = __builtin_amdgcn_udot4(bh, 0x01010101u, b_h[k], false);
+      bb_ll[k] = __builtin_amdgcn_udot4(bl, bl, bb_ll[k], false);
+      bb_lh[k] = __builtin_amdgcn_udot4(bl, bh, bb_lh[k], false);
+      bb_hh[k] = __builtin_amdgcn_udot4(bh, bh, bb_hh[k], false);
+      ab_ll[k] = __builtin_amdgcn_udot4(al, bl, ab_ll[k], false);
+      ab_x[k] = __builtin_amdgcn_udot4(al, bh, ab_x[k], false);
+      ab_x[k] = __builtin_amdgcn_udot4(ah, bl, ab_x[k], false);
+      ab_hh[k] = __builtin_amdgcn_udot4(ah, bh, ab_hh[k], false);
+    };
+    if constexpr (LA) lag(0, x0, x1);
+    if constexpr (LB) lag(1, y0, y1);
+  }
+  __device__ __forceinline__ void planes(int k, unsigned (&v)[kPlanes]) const {
+    v[0] = a_l, v[1] = a_h, v[2] = b_l[k], v[3] = b_h[k], v[4] = aa_ll, v[5] = aa_lh, v[6] = aa_hh;
+    v[7] = bb_ll[k], v[8] = bb_lh[k], v[9] = bb_hh[k], v[10] = ab_ll[k], v[11] = ab_x[k], v[12] = ab_hh[k];
+  }
+};
+
+// The planes of the lanes with `take` set, summed over each DPP row and added to dst[0..13) (LDS).
+__device__ __forceinline__ void add_planes(const unsigned (&v)[kPlanes], bool take, unsigned long long* dst) {
+  const bool writer = (threadIdx.x & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < kPlanes; ++i) {
+    const unsigned t = row_sum(take ? v[i] : 0u);
+    if (writer && t != 0u) atomicAdd(&dst[i], (unsigned long long)t);
+  }
+}
+
+template <bool LA, bool LB>
+__device__ __forceinline__ void sweep_rows(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, int64_t pitch,
+                                           int r0, int r1, int off_a, int off_b, SweepAcc& acc) {
+  // a, b: the lane's group in row 0 of the first strip / the start of the paired row of the second
+  int r = r0;
+#pragma unroll 1
+  for (; r + 1 < r1; r += 2) {  // two rows per trip: six 16-byte loads in flight per lane
+    const uint16_t* ar = a + (int64_t)r * pitch;
+    const uint16_t* br = b + (int64_t)r * pitch;
+    const U16x8 va0 = *reinterpret_cast<const U16x8*>(ar), va1 = *reinterpret_cast<const U16x8*>(ar + pitch);
+    U16x8 xa0{}, xa1{}, xb0{}, xb1{};
+    if constexpr (LA) {
+      xa0 = *reinterpret_cast<const U16x8*>(br + off_a);
+      xa1 = *reinterpret_cast<const U16x8*>(br + pitch + off_a);
+    }
+    if constexpr (LB) {
+      xb0 = *reinterpret_cast<const U16x8*>(br + off_b);
+      xb1 = *reinterpret_cast<const U16x8*>(br + pitch + off_b);
+    }
+    acc.add4<LA, LB>(va0.d[0], va0.d[1], xa0.d[0], xa0.d[1], xb0.d[0], xb0.d[1]);
+    acc.add4<LA, LB>(va0.d[2], va0.d[3], xa0.d[2], xa0.d[3], xb0.d[2], xb0.d[3]);
+    acc.add4<LA, LB>(va1.d[0], va1.d[1], xa1.d[0], xa1.d[1], xb1.d[0], xb1.d[1]);
+    acc.add4<LA, LB>(va1.d[2], va1.d[3], xa1.d[2], xa1.d[3], xb1.d[2], xb1.d[3]);
+  }
+  if (r < r1) {
+    const uint16_t* ar = a + (int64_t)r * pitch;
+    const uint16_t* br = b + (int64_t)r * pitch;
+    const U16x8 va0 = *reinterpret_cast<const U16x8*>(ar);
+    U16x8 xa0{}, xb0{};
+    if constexpr (LA) xa0 = *reinterpret_cast<const U16x8*>(br + off_a);
+    if constexpr (LB) xb0 = *reinterpret_cast<const U16x8*>(br + off_b);
+    acc.add4<LA, LB>(va0.d[0], va0.d[1], xa0.d[0], xa0.d[1], xb0.d[0], xb0.d[1]);
+    acc.add4<LA, LB>(va0.d[2], va0.d[3], xa0.d[2], xa0.d[3], xb0.d[2], xb0.d[3]);
+  }
+}
+
+__global__ __launch_bounds__(kThreads, MS_SWEEP_OCC) void k_ncc_sweep(const PairDesc* desc, const int8_t* status, int pair0,
+                                                                      int n_in_pass, const Peak* peaks, const Cand* cand,
+                                                                      unsigned long long* acc, int n_cand, int n_peaks,
+                                                                      int n_row_chunks, int n_col_chunks) {
+  __shared__ unsigned long long red[4][kPlanes + 1];  // [2 * lag + side of the wrap column][byte plane]
+  __shared__ unsigned long long red2[5 * kThreads / 64];
+  const int tid = threadIdx.x;
+  const int xcd = blockIdx.x % kXcds, seq = blockIdx.x / kXcds;
+  const int per_pair = n_peaks * 2 * n_row_chunks * n_col_chunks;
+  const int pz = xcd + kXcds * (seq / per_pair);
+  if (pz >= n_in_pass) return;
+  int within = seq % per_pair;
+  const int cc = within % n_col_chunks;
+  within /= n_col_chunks;
+  const int ch = within % n_row_chunks;
+  within /= n_row_chunks;
+  const int sig = within & 1, pk = within >> 1;
+  const int p = pair0 + pz;
+  const int8_t st = status[p];
+  const Peak peak = peaks[(int64_t)p * kMaxK + pk];
+  const PairDesc d = desc[p];
+  if (st != MISTITCH_PAIR_OK || peak.key < 0) return;
+  const int py = peak.key / d.img_w, px = peak.key - py * d.img_w;
+  const int n = d.transposed ? px : py, m = d.transposed ? py : px;  // canonical rows, columns: 0 <= n < S, 0 <= m < L
+  const int S = d.S, L = d.L;
+  // rows: lag +n pairs row r with row r - n (r >= n: shift +n) or r - n + S (r < n: shift -(S - n)); lag -n pairs it
+  // with r + n (r < S - n: shift -n) or r + n - S (shift +(S - n))
+  const int wrap_row = sig ? S - n : n;
+  const int n_below = (wrap_row + kSweepRows - 1) / kSweepRows;  // chunks of the rows before the wrap
+  const bool below = ch < n_below;
+  const int r0 = below ? ch * kSweepRows : wrap_row + (ch - n_below) * kSweepRows;
+  const int r1 = min(r0 + kSweepRows, below ? wrap_row : S);
+  if (r0 >= r1) return;
+  const int row_mag = (sig != 0) != below ? 1 : 0;  // 0: magnitude n, 1: S - n
+  const int row_pos = below ? 0 : 1;                // sign of the row shift
+  const int ds = (row_pos ? 1 : -1) * (row_mag ? S - n : n);
+  // the four candidates of this workgroup, q = 2 * lag + side: lag 0 reads the second strip at column (c - m) mod L
+  // (side 1, c >= m: shift +m; side 0: shift -(L - m)), lag 1 at (c + m) mod L (side 0, c < L - m: shift -m; side 1:
+  // shift +(L - m))
+  const int slots = n_cand + 1;
+  int ci[4], dl[4];
+  bool live[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int lag = q >> 1, side = q & 1;
+    const int col_mag = lag ? side : 1 - side;
+    const int col_pos = side;
+    dl[q] = (col_pos ? 1 : -1) * (col_mag ? L - m : m);
+    const int t = d.transposed ? (col_mag << 3) | (row_mag << 2) | (col_pos << 1) | row_pos
+                               : (row_mag << 3) | (col_mag << 2) | (row_pos << 1) | col_pos;
+    ci[q] = 16 * pk + t;
+    live[q] = cand[(int64_t)p * slots + ci[q]].flag == 0;
+  }
+  const bool lag_a = live[0] | live[1], lag_b = live[2] | live[3];
+  if (!(lag_a | lag_b)) return;
+  const int ngroups = L >> 3;
+  const int g0 = cc * kThreads;  // first group of this column chunk
+  // the groups the wrap columns cut (-1: none, or not in this chunk, or a lag without a live candidate)
+  int cut_a = (lag_a && (m & 7)) ? (m >> 3) : -1;
+  int cut_b = (lag_b && ((L - m) & 7)) ? ((L - m) >> 3) : -1;
+  if (cut_a >= 0 && cut_a == cut_b) {
+    // both wrap columns cut the same group (m within 8 of L / 2): the four overlaps one by one, windowed as
+    // k_ncc_accumulate does, by the workgroups of the first column chunk
+    if (cc != 0) return;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+      if (!live[q]) continue;  // uniform
+      const int l_lo = dl[q] > 0 ? dl[q] : 0, l_hi = L + (dl[q] < 0 ? dl[q] : 0);
+      unsigned long long v[5];
+      moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl[q]), d.pitch, r0, r1, 1, l_hi - l_lo, v);
+      __syncthreads();
+      reduce_moments(v, red2, acc + ((int64_t)p * slots + ci[q]) * 5);
+    }
+    return;
+  }
+  if (cut_a < g0 || cut_a >= g0 + kThreads) cut_a = -1;
+  if (cut_b < g0 || cut_b >= g0 + kThreads) cut_b = -1;
+  if (tid < 4 * (kPlanes + 1)) red[tid / (kPlanes + 1)][tid % (kPlanes + 1)] = 0ull;
+  const int gidx = g0 + tid;
+  const bool active = gidx < ngroups;
+  const int c = active ? 8 * gidx : 0;
+  // side of the lane's group for either lag (2: its sums are not used) and where its second-strip pixels start
+  int off_a = 0, off_b = 0, side_a = 2, side_b = 2;
+  if (active && gidx != cut_a) {
+    side_a = c >= m ? 1 : 0;
+    off_a = c >= m ? c - m : c - m + L;
+  }
+  if (active && gidx != cut_b) {
+    side_b = c + m >= L ? 1 : 0;
+    off_b = c + m >= L ? c + m - L : c + m;
+  }
+  SweepAcc sa;
+  const uint16_t* a_lane = d.a + c;
+  const uint16_t* b_rows = d.b + (int64_t)(-ds) * d.pitch;  // row r of the first strip meets row r - ds of the second
+  if (lag_a && lag_b)
+    sweep_rows<true, true>(a_lane, b_rows, d.pitch, r0, r1, off_a, off_b, sa);
+  else if (lag_a)
+    sweep_rows<true, false>(a_lane, b_rows, d.pitch, r0, r1, off_a, off_b, sa);
+  else
+    sweep_rows<false, true>(a_lane, b_rows, d.pitch, r0, r1, off_a, off_b, sa);
+  __syncthreads();  // red is zero
+#pragma unroll
+  for (int lag = 0; lag < 2; ++lag) {
+    if (!(lag ? lag_b : lag_a)) continue;  // uniform
+    const int side = lag ? side_b : side_a;
+    unsigned v[kPlanes];
+    sa.planes(lag, v);
+#pragma unroll
+    for (int sd = 0; sd < 2; ++sd) {
+      if (__ballot(side == sd) == 0ull) continue;  // wave-uniform: no lane of this wave on that side
+      add_planes(v, side == sd, red[2 * lag + sd]);
+    }
+  }
+  // the cut groups, pixel by pixel: wave w takes the pixels of lag w / 2 on side w % 2 (before the wrap: side 0 for
+  // either lag), lane l pixel l % 8 of them in rows r0 + l / 8, + 8, ...
+  {
+    const int w = tid >> 6, lane = tid & 63;
+    const int lag = w >> 1, sd = w & 1;
+    const int cut = lag ? cut_b : cut_a;
+    if (cut >= 0) {  // wave-uniform
+      const int shift = lag ? m : -m;
+      const int first = 8 * cut;
+      const int before = lag ? L - m - first : m - first;  // pixels of the group before the wrap: 1..7
+      const int i = (lane & 7) + (sd ? before : 0);
+      const bool mine = sd ? i < 8 : i < before;
+      int bc = first + i + shift;
+      bc += bc < 0 ? L : 0;
+      bc -= bc >= L ? L : 0;
+      MomentAcc ma;
+      if (mine) {
+        for (int r = r0 + (lane >> 3); r < r1; r += 8)
+          ma.add1(d.a[(int64_t)r * d.pitch + first + i], b_rows[(int64_t)r * d.pitch + bc]);
+      }
+      const unsigned v[kPlanes] = {ma.a_l,   ma.a_h,   ma.b_l,   ma.b_h,   ma.aa_ll, ma.aa_lh, ma.aa_hh,
+                                   ma.bb_ll, ma.bb_lh, ma.bb_hh, ma.ab_ll, ma.ab_x,  ma.ab_hh};
+      add_planes(v, true, red[2 * lag + sd]);
+    }
+  }
+  __syncthreads();
+  if (tid < 20) {
+    const int q = tid / 5, i = tid % 5;
+    const unsigned long long* pl = red[q];
+    unsigned long long v;
+    if (i == 0) v = pl[0] + (pl[1] << 8);
+    else if (i == 1) v = pl[2] + (pl[3] << 8);
+    else if (i == 2) v = pl[4] + (pl[5] << 9) + (pl[6] << 16);
+    else if (i == 3) v = pl[7] + (pl[8] << 9) + (pl[9] << 16);
+    else v = pl[10] + (pl[11] << 8) + (pl[12] << 16);
+    bool alive = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) alive = (k == q) ? live[k] : alive;
+    int slot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) slot = (k == q) ? ci[k] : slot;
+    if (alive && v != 0ull) atomicAdd(&acc[((int64_t)p * slots + slot) * 5 + i], v);
+  }
 }
 
 // ---- exact 128-bit helpers -------------------------------------------------
@@ -4062,10 +4338,27 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
     }
     return MISTITCH_OK;
   };
+  // The signed interpretations of the peaks are summed by circular sweeps when every canonical line starts on a 16-byte
+  // boundary and holds whole 8-pixel groups; the subpixel slot, and everything otherwise, by windows.
+#ifndef MS_NCC_SWEEP
+#define MS_NCC_SWEEP 1
+#endif
+  const bool sweep = MS_NCC_SWEEP && H % 8 == 0 && W % 8 == 0 && aligned16(ws.staging) && slot_elems % 8 == 0 &&
+                     (ff != nullptr || vec_top);
   auto candidates = [&](int pair0, int n) {
-    MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate,
-              dim3(kXcds * ((n + kXcds - 1) / kXcds) * (ws.n_cand + 1) * kNccChunks), dim3(kThreads), 0, ws.desc, status, pair0,
-              n, ws.cand, ws.acc, ws.n_cand);
+    const unsigned pair_groups = kXcds * ((n + kXcds - 1) / kXcds);
+    if (sweep) {
+      const int s_max = std::max(w_left, w_top), l_max = std::max(H, W);
+      const int n_row_chunks = (s_max + kSweepRows - 1) / kSweepRows + 1, n_col_chunks = (l_max / 8 + kThreads - 1) / kThreads;
+      MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_sweep, dim3(pair_groups * k * 2 * n_row_chunks * n_col_chunks), dim3(kThreads), 0,
+                ws.desc, status, pair0, n, ws.peaks, ws.cand, ws.acc, ws.n_cand, k, n_row_chunks, n_col_chunks);
+      if (subpixel)
+        MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(pair_groups * kNccChunks), dim3(kThreads), 0, ws.desc, status,
+                  pair0, n, ws.cand, ws.acc, ws.n_cand, ws.n_cand, 1);
+    } else {
+      MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(pair_groups * (ws.n_cand + 1) * kNccChunks), dim3(kThreads), 0,
+                ws.desc, status, pair0, n, ws.cand, ws.acc, ws.n_cand, 0, ws.n_cand + 1);
+    }
   };
   if (stage_all && (rc = stage(0, n_pairs))) return rc;
   for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {

@@ -192,6 +192,17 @@ def fuzz_consensus(rng, reg, oreg, synth):
     edge = int(rng.choice([4, 6, 8, 12, 16, 32, int(rng.integers(4, 40))]))
     g = synth.make_grid(int(rng.integers(1 << 30)), rows, cols, th, tw, overlap=float(rng.uniform(0.1, 0.3)),
                         jitter=int(rng.integers(1, 4)), lowpass=float(rng.choice([0, 200, 2000, 8000])))
+    # A scene that does not vary along one axis (a low-passed scene of few rows) has a correlation matrix of exactly
+    # tied peaks; which ten of them rank first is then NumPy's unstable sort against this library's, not a property of
+    # either: such grids are not compared.
+    for p, (i1, i2) in enumerate(g.pair_idx):
+        e1, e2, _, _ = oreg.edge_strips(g.tiles[i1], g.tiles[i2], "top" if g.pair_dir[p] else "left", edge)
+        if e1.size == 0 or min(e1.shape) < 2:
+            continue
+        vals = oreg.multi_peak_max(oreg.pcm(e1, e2))[2][:12]
+        if np.any(np.abs(np.diff(vals)) <= 1e-9 * np.abs(vals[:-1])):
+            STATS["consensus_tied_peaks_skipped"] = STATS.get("consensus_tied_peaks_skipped", 0) + 1
+            return True, dict(kind="consensus", skipped="tied peaks"), None
     out, st = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, consensus=True)
     out, st = out.cpu().numpy(), st.cpu().numpy()
     exp, exp_st, stood = oreg.register_pairs_consensus(g.tiles, g.pair_idx, g.pair_dir, edge)
@@ -200,6 +211,10 @@ def fuzz_consensus(rng, reg, oreg, synth):
     good = bool(np.array_equal(st != 0, exp_st != 0))
     ok = exp_st == 0
     good = good and np.array_equal(out[ok, 1:], exp[ok, 1:]) and np.allclose(out[ok, 0], exp[ok, 0], rtol=0, atol=1e-9)
+    if not good and os.environ.get("FUZZ_DUMP"):   # the inputs of the failing case, for a closer look
+        _, _, table = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, consensus=True, return_candidates=True)
+        np.savez_compressed(os.environ["FUZZ_DUMP"], tiles=g.tiles, pair_idx=g.pair_idx, pair_dir=g.pair_dir, edge=edge,
+                            out=out, st=st, exp=exp, exp_st=exp_st, table=table.cpu().numpy())
     return bool(good), dict(kind="consensus", grid=(rows, cols), tile=(th, tw), edge=edge), (out, st, exp, exp_st)
 
 
