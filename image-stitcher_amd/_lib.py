@@ -36,6 +36,7 @@ EXPORTS = [
     "mistitch_profile_enable", "mistitch_profile_collect", "mistitch_subpixel_shift",
     "mistitch_set_upsample_factor", "mistitch_pyramid", "mistitch_chunk_layout", "mistitch_refine_pairs",
     "mistitch_register_pairs_flatfield", "mistitch_fuse_static", "mistitch_register_pairs_candidates",
+    "mistitch_bitshuffle",
 ]
 
 
@@ -76,6 +77,7 @@ def _load() -> C.CDLL:
         "mistitch_mip": [vp, vp, i32, i64, i64, vp],
         "mistitch_pyramid": [vp, vp, i32, i32, i32, i32, C.POINTER(vp)],
         "mistitch_chunk_layout": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
+        "mistitch_bitshuffle": [vp, vp, vp, i64, i32, i64],
         "mistitch_synchronize": [vp],
         "mistitch_profile_enable": [vp, i32],
         "mistitch_profile_collect": [vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(i32), i32,

@@ -1138,8 +1138,10 @@ struct __attribute__((packed, aligned(8))) ChunkGroup8 {
 };
 template <int ES, bool VEC>
 __global__ __launch_bounds__(256) void k_chunk_layout(const unsigned char* __restrict__ image, int h, int w, int chunk_h,
-                                                      int chunk_w, int ncy, int ncx, unsigned char* __restrict__ out) {
-  const int64_t row_id = blockIdx.x;  // ((plane * ncy + cy) * ncx + cx) * chunk_h + r
+                                                      int chunk_w, int ncy, int ncx, int64_t n_rows,
+                                                      unsigned char* __restrict__ out) {
+  const int64_t row_id = (int64_t)blockIdx.y * gridDim.x + blockIdx.x;  // ((plane * ncy + cy) * ncx + cx) * chunk_h + r
+  if (row_id >= n_rows) return;
   const int r = (int)(row_id % chunk_h);
   const int64_t chunk_id = row_id / chunk_h;
   const int cx = (int)(chunk_id % ncx);
@@ -1193,20 +1195,155 @@ extern "C" int mistitch_chunk_layout(mistitch_ctx* ctx, const void* image, int e
   MS_REQUIRE(n_planes > 0 && h > 0 && w > 0 && chunk_h > 0 && chunk_w > 0, MISTITCH_ERR_ARG, "bad geometry");
   const int ncy = (h + chunk_h - 1) / chunk_h, ncx = (w + chunk_w - 1) / chunk_w;
   const int64_t rows = (int64_t)n_planes * ncy * ncx * chunk_h;
-  MS_REQUIRE(rows <= 0x7fffffffll, MISTITCH_ERR_UNSUPPORTED, "%lld chunk rows exceed one launch", (long long)rows);
+  MS_REQUIRE(rows <= (65535ll << 20), MISTITCH_ERR_UNSUPPORTED, "%lld chunk rows exceed one launch", (long long)rows);
   MS_HIP(hipSetDevice(ctx->device));
   const bool vec = ((int64_t)chunk_w * elem_size) % 16 == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0 &&
                    (reinterpret_cast<uintptr_t>(image) % (uintptr_t)elem_size) == 0;
   const unsigned char* src = reinterpret_cast<const unsigned char*>(image);
   unsigned char* dst = reinterpret_cast<unsigned char*>(out);
-  const dim3 grid((unsigned)rows);
+  // one workgroup per chunk row, in a two-dimensional grid: a launch holds fewer than 2^32 threads along x
+  constexpr int64_t kRowsX = 1 << 20;
+  const dim3 grid((unsigned)std::min<int64_t>(rows, kRowsX), (unsigned)((rows + kRowsX - 1) / kRowsX));
   if (elem_size == 2) {
-    if (vec) MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<2, true>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, dst);
-    else MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<2, false>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, dst);
+    if (vec) MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<2, true>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, rows, dst);
+    else MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<2, false>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, rows, dst);
   } else {
-    if (vec) MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<8, true>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, dst);
-    else MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<8, false>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, dst);
+    if (vec) MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<8, true>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, rows, dst);
+    else MS_LAUNCH(ctx, "k_chunk_layout", (k_chunk_layout<8, false>), grid, dim3(256), 0, src, h, w, chunk_h, chunk_w, ncy, ncx, rows, dst);
   }
+  MS_HIP(hipGetLastError());
+  return MISTITCH_OK;
+}
+
+// ---- bitshuffle filter ---------------------------------------------------------------------------
+// The reference's default chunk compressor is Blosc(cname='zstd', clevel=5, shuffle=BITSHUFFLE)
+// (stitcher.py:536, :549).  Blosc cuts a chunk into blocks and, before the entropy coder sees a block, applies the
+// bitshuffle filter to it: the block's whole groups of 8 elements are transposed as a bit matrix, so that
+// out[(8 b + k) * (n / 8) + g] holds bit k of byte b of the elements 8 g .. 8 g + 7 (element 8 g + i in bit i), for
+// n = the block's element count rounded down to a multiple of 8; the bytes after those n elements are copied.
+// That filter is a streaming pass and is what this kernel does on the device; the entropy coder (zstd) stays with the
+// caller's codec library.
+// A workgroup takes 2048 elements of one block: lane t transposes the 8 x 8 bit matrices of its 8 elements (one per
+// byte of the element) and leaves their rows in LDS, from where whole 16-byte pieces of the output rows are written.
+constexpr int kShufElems = 2048;  // elements per workgroup
+__device__ __forceinline__ unsigned long long transpose_bits_8x8(unsigned long long x) {
+  unsigned long long t;
+  t = (x ^ (x >> 7)) & 0x00AA00AA00AA00AAull;
+  x = x ^ t ^ (t << 7);
+  t = (x ^ (x >> 14)) & 0x0000CCCC0000CCCCull;
+  x = x ^ t ^ (t << 14);
+  t = (x ^ (x >> 28)) & 0x00000000F0F0F0F0ull;
+  x = x ^ t ^ (t << 28);
+  return x;
+}
+
+template <int ES>
+__global__ __launch_bounds__(256) void k_bitshuffle(const unsigned char* __restrict__ in, unsigned char* __restrict__ out,
+                                                    int64_t n_bytes, int64_t block_bytes, int tiles_per_block, int vec_whole) {
+  constexpr int kRows = 8 * ES;
+  constexpr int kStride = 256 + 16;  // bytes per LDS row: 16-byte pieces stay aligned, rows fall into different banks
+  __shared__ __align__(16) unsigned char rows[kRows * kStride];
+  const int t = threadIdx.x;
+  const int64_t blk = blockIdx.x / tiles_per_block;
+  const int tile = blockIdx.x % tiles_per_block;
+  const int64_t blk_off = blk * block_bytes;
+  const int64_t bytes = min(block_bytes, n_bytes - blk_off);
+  const bool vec = vec_whole && bytes == block_bytes;  // 16-byte accesses: whole blocks only (the last one may be short)
+  const int64_t n_main = (bytes / ES) & ~(int64_t)7;  // elements that are transposed
+  const int64_t row_bytes = n_main / 8;
+  const unsigned char* src = in + blk_off;
+  unsigned char* dst = out + blk_off;
+  if (tile == 0) {  // what follows the whole groups of 8 elements is copied
+    for (int64_t i = n_main * ES + t; i < bytes; i += 256) dst[i] = src[i];
+  }
+  const int64_t e0 = (int64_t)tile * kShufElems + 8 * t;  // first element of this lane
+  if ((int64_t)tile * kShufElems >= n_main) return;        // uniform
+  unsigned long long plane[ES];  // plane[b]: byte b of the lane's 8 elements, element i in byte i
+#pragma unroll
+  for (int b = 0; b < ES; ++b) plane[b] = 0ull;
+  if (e0 < n_main) {
+    const unsigned char* p = src + e0 * ES;
+    if (vec) {  // 16-byte loads (the block starts are 16-byte aligned)
+      unsigned w[2 * ES];
+#pragma unroll
+      for (int q = 0; q < ES / 2 + (ES == 1 ? 1 : 0); ++q) {
+        if constexpr (ES >= 2) {
+          const uint4 v = *reinterpret_cast<const uint4*>(p + 16 * q);
+          w[4 * q] = v.x, w[4 * q + 1] = v.y, w[4 * q + 2] = v.z, w[4 * q + 3] = v.w;
+        } else {
+          const uint2 v = *reinterpret_cast<const uint2*>(p);
+          w[0] = v.x, w[1] = v.y;
+        }
+      }
+      // element i occupies bytes [i * ES, (i + 1) * ES) of w
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int b = 0; b < ES; ++b) {
+          const int at = i * ES + b;
+          plane[b] |= (unsigned long long)((w[at >> 2] >> (8 * (at & 3))) & 0xffu) << (8 * i);
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int b = 0; b < ES; ++b) plane[b] |= (unsigned long long)p[i * ES + b] << (8 * i);
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < ES; ++b) {
+    const unsigned long long x = transpose_bits_8x8(plane[b]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) rows[(8 * b + k) * kStride + t] = (unsigned char)(x >> (8 * k));
+  }
+  __syncthreads();
+  // row r of the tile is bytes [tile * 256, +256) of output row r; 16 pieces of 16 bytes each
+  const int64_t col0 = (int64_t)tile * (kShufElems / 8);
+  for (int q = t; q < kRows * 16; q += 256) {
+    const int r = q >> 4, seg = q & 15;
+    const int64_t col = col0 + 16 * seg;
+    if (col >= row_bytes) continue;
+    unsigned char* o = dst + (int64_t)r * row_bytes + col;
+    const unsigned char* l = rows + r * kStride + 16 * seg;
+    if (vec && col + 16 <= row_bytes) {
+      *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(l);
+    } else {
+      const int nb = (int)min((int64_t)16, row_bytes - col);
+      for (int i = 0; i < nb; ++i) o[i] = l[i];
+    }
+  }
+}
+
+extern "C" int mistitch_bitshuffle(mistitch_ctx* ctx, const void* in, void* out, int64_t n_bytes, int elem_size,
+                                   int64_t block_bytes) {
+  MS_REQUIRE(ctx && in && out, MISTITCH_ERR_ARG, "NULL argument");
+  MS_REQUIRE(in != out, MISTITCH_ERR_ARG, "the filter does not work in place");
+  MS_REQUIRE(elem_size == 1 || elem_size == 2 || elem_size == 4 || elem_size == 8, MISTITCH_ERR_UNSUPPORTED,
+             "elements of %d bytes", elem_size);
+  MS_REQUIRE(n_bytes >= 0 && block_bytes > 0 && block_bytes % elem_size == 0, MISTITCH_ERR_ARG,
+             "block size %lld is not a positive multiple of the element size", (long long)block_bytes);
+  if (n_bytes == 0) return MISTITCH_OK;
+  MS_HIP(hipSetDevice(ctx->device));
+  const int64_t n_blocks = (n_bytes + block_bytes - 1) / block_bytes;
+  const int64_t block_elems = std::min(block_bytes, n_bytes) / elem_size;
+  const int tiles = (int)std::max<int64_t>(1, (block_elems + kShufElems - 1) / kShufElems);
+  MS_REQUIRE(n_blocks * tiles <= 0x7fffffffll, MISTITCH_ERR_UNSUPPORTED, "%lld workgroups exceed one launch",
+             (long long)(n_blocks * tiles));
+  // 16-byte accesses: every block starts on a 16-byte boundary and every output row of a whole block does too
+  const int64_t main_full = (block_bytes / elem_size) & ~(int64_t)7;
+  const int vec = (reinterpret_cast<uintptr_t>(in) % 16 == 0 && reinterpret_cast<uintptr_t>(out) % 16 == 0 &&
+                   block_bytes % 16 == 0 && (main_full / 8) % 16 == 0)
+                      ? 1
+                      : 0;
+  const unsigned char* src = reinterpret_cast<const unsigned char*>(in);
+  unsigned char* dst = reinterpret_cast<unsigned char*>(out);
+  const dim3 grid((unsigned)(n_blocks * tiles));
+#define MS_SHUF(E) MS_LAUNCH(ctx, "k_bitshuffle", k_bitshuffle<E>, grid, dim3(256), 0, src, dst, n_bytes, block_bytes, tiles, vec)
+  if (elem_size == 1) MS_SHUF(1);
+  else if (elem_size == 2) MS_SHUF(2);
+  else if (elem_size == 4) MS_SHUF(4);
+  else MS_SHUF(8);
+#undef MS_SHUF
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }

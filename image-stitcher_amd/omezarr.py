@@ -68,6 +68,38 @@ def chunk_layout(image, chunk_h: int, chunk_w: int, ctx=None):
     return out
 
 
+def bitshuffle(buf, elem_size: int, block_bytes: int = 1 << 18, ctx=None):
+    """Blosc's bitshuffle filter of a device buffer (any shape, viewed as bytes): the first stage of the reference's
+    default chunk compressor (Blosc zstd level 5 with BITSHUFFLE, stitcher.py:536, :549).  ``block_bytes`` is the
+    codec's block size (the filter works block by block); returns a uint8 tensor of the same byte length.  Chunks
+    filtered here go to the entropy coder with its own shuffle switched off."""
+    torch = _torch()
+    if not buf.is_cuda:
+        raise ValueError("a device tensor is expected")
+    src = buf.contiguous()
+    n_bytes = src.numel() * src.element_size()
+    out = torch.empty((n_bytes,), dtype=torch.uint8, device=src.device)
+    c = ctx or _lib.default_context()
+    check(lib.mistitch_bitshuffle(c.handle, ptr(src), ptr(out), n_bytes, int(elem_size), int(block_bytes)))
+    return out
+
+
+def bitshuffle_numpy(block: np.ndarray, elem_size: int, block_bytes: int = 1 << 18) -> np.ndarray:
+    """The filter's definition in NumPy (the check of ``bitshuffle``): per block, the leading whole groups of 8
+    elements as a transposed bit matrix (bit k of byte b of element 8 g + i -> row 8 b + k, byte g, bit i), the
+    remaining bytes copied."""
+    raw = np.ascontiguousarray(block).view(np.uint8).reshape(-1)
+    out = np.empty_like(raw)
+    for off in range(0, raw.size, block_bytes):
+        part = raw[off:off + block_bytes]
+        n = (part.size // elem_size) & ~7
+        if n:
+            bits = np.unpackbits(part[:n * elem_size].reshape(n, elem_size), axis=1, bitorder="little")
+            out[off:off + n * elem_size] = np.packbits(bits.T, axis=1, bitorder="little").reshape(-1)
+        out[off + n * elem_size:off + part.size] = part[n * elem_size:]
+    return out
+
+
 def multiscales_attrs(name: str, n_levels: int, px_um: float, dz_um: float = 1.0) -> List[dict]:
     """The ``multiscales`` attribute: axes and per-level scale transforms as stitcher.py:489-523, :604-617."""
     datasets = []

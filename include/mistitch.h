@@ -310,6 +310,19 @@ int mistitch_pyramid(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int
 int mistitch_chunk_layout(mistitch_ctx* ctx, const void* image, int elem_size, int n_planes, int h, int w,
                           int chunk_h, int chunk_w, void* out);
 
+/* Blosc's BITSHUFFLE filter on the device: the first stage of the reference's default chunk compressor,
+ * Blosc(cname='zstd', clevel=5, shuffle=Blosc.BITSHUFFLE) (stitcher.py:536, :549), which numcodecs applies to every
+ * chunk on the host.  The buffer is taken in blocks of block_bytes (the codec's block size; the last block may be
+ * shorter); inside a block the n = floor(elements / 8) * 8 leading elements are transposed as a bit matrix,
+ *   out[(8 b + k) * (n / 8) + g] = bit k of byte b of elements 8 g .. 8 g + 7, element 8 g + i in bit i,
+ * and the bytes behind them are copied (bitshuffle's bshuf_trans_bit_elem as c-blosc drives it).  The entropy coder
+ * itself (zstd) and the Blosc container stay with the caller's codec library: chunks filtered here are compressed with
+ * shuffle off.  Neither numcodecs nor c-blosc is available to check against: tested against a NumPy statement of the
+ * definition above only.
+ *   in, out    n_bytes each, device memory, not aliased;  elem_size 1, 2, 4 or 8                                  */
+int mistitch_bitshuffle(mistitch_ctx* ctx, const void* in, void* out, int64_t n_bytes, int elem_size,
+                        int64_t block_bytes);
+
 /* Per-kernel timing with HIP events recorded on the context's stream around
  * every launch (measurement aid; no counterpart in the reference).  Enable,
  * run any entry points, then collect: kernel names come back '\n'-separated in

@@ -97,3 +97,51 @@ def test_written_store_reads_back(tmp_path):
         # every chunk file is one whole chunk
         f = os.path.join(path, str(level), "0", "1", "2", "0", "0")
         assert os.path.getsize(f) == 128 * 256 * (2 if level == 0 else 8)
+
+
+def test_bitshuffle_definition_on_hand_worked_blocks():
+    """The NumPy statement of Blosc's bitshuffle filter (the device kernel's check) on blocks small enough to work by
+    hand.  c-blosc / numcodecs are not importable: parity with their output unpinned."""
+    # eight 1-byte elements, element i = 1 << i: bit k is set in element k only -> row k = the byte with bit k set
+    one = np.array([1 << i for i in range(8)], dtype=np.uint8)
+    assert omezarr.bitshuffle_numpy(one, 1, 8).tolist() == [1 << k for k in range(8)]
+    # sixteen uint16 elements, all 0x0100 except element 9 = 0x8003: rows of 2 bytes, row 8 b + k
+    v = np.full(16, 0x0100, dtype=np.uint16)
+    v[9] = 0x8003
+    out = omezarr.bitshuffle_numpy(v, 2, 32).reshape(16, 2)
+    assert out[0].tolist() == [0, 0b10] and out[1].tolist() == [0, 0b10]              # bits 0, 1 of the low byte: element 9
+    assert out[8].tolist() == [0xFF, 0xFF & ~0b10]                                    # bit 0 of the high byte: all but 9
+    assert out[15].tolist() == [0, 0b10] and not out[2:8].any() and not out[9:15].any()
+    # 11 elements: the first 8 are transposed, the last 3 copied; a second, short block of 5 elements is copied whole
+    w = np.arange(16, dtype=np.uint16) * 257
+    got = omezarr.bitshuffle_numpy(w, 2, 22)
+    assert np.array_equal(got[:16], omezarr.bitshuffle_numpy(w[:8], 2, 16)) and np.array_equal(got[16:22], w[8:11].view(np.uint8))
+    assert np.array_equal(got[22:], w[11:].view(np.uint8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_elems,elem_size,block_bytes", [(128 * 256, 2, 128 * 256 * 2),   # one chunk, one block
+                                                           (1 << 20, 2, 1 << 18),          # whole 256 KiB blocks: 16-byte path
+                                                           (3 * 4096 + 2048 + 77, 2, 8192),  # short last block with a tail
+                                                           (5000, 8, 4096),                 # float64 level, 512-element blocks
+                                                           (40000, 8, 1 << 18),             # float64, one short block
+                                                           (1000, 4, 256), (777, 1, 100), (4096 + 13, 2, 1 << 16),
+                                                           (7, 2, 64), (8, 2, 64)])
+def test_bitshuffle_on_the_device_matches_the_definition(n_elems, elem_size, block_bytes):
+    import torch
+    rng = np.random.default_rng(n_elems)
+    raw = rng.integers(0, 256, size=n_elems * elem_size, dtype=np.uint8)
+    got = omezarr.bitshuffle(torch.from_numpy(raw).cuda(), elem_size, block_bytes).cpu().numpy()
+    assert np.array_equal(got, omezarr.bitshuffle_numpy(raw, elem_size, block_bytes))
+
+
+@pytest.mark.gpu
+def test_bitshuffle_of_a_laid_out_chunk():
+    """A chunk as the writer hands it out (chunk_layout), filtered block by block as the codec would."""
+    import torch
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 4096, size=(1, 300, 520), dtype=np.uint16)
+    laid = omezarr.chunk_layout(torch.from_numpy(img.view(np.int16)).cuda().view(torch.uint16), 128, 256)
+    chunk = laid[0, 1, 1]
+    got = omezarr.bitshuffle(chunk, 2, 1 << 14).cpu().numpy()
+    assert np.array_equal(got, omezarr.bitshuffle_numpy(_np_chunks(img, 128, 256)[0, 1, 1], 2, 1 << 14))
