@@ -36,7 +36,7 @@ EXPORTS = [
     "mistitch_profile_enable", "mistitch_profile_collect", "mistitch_subpixel_shift",
     "mistitch_set_upsample_factor", "mistitch_pyramid", "mistitch_chunk_layout", "mistitch_refine_pairs",
     "mistitch_register_pairs_flatfield", "mistitch_fuse_static", "mistitch_register_pairs_candidates",
-    "mistitch_bitshuffle",
+    "mistitch_bitshuffle", "mistitch_fuse_chunked", "mistitch_pyramid_chunked",
 ]
 
 
@@ -74,8 +74,10 @@ def _load() -> C.CDLL:
         "mistitch_apply_flatfield": [vp, vp, vp, i32, vp, i32, i32, i32],
         "mistitch_fuse": [vp, vp, i32, i32, i32, i64, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32],
         "mistitch_fuse_static": [vp, vp, i32, i32, i32, i64, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32],
+        "mistitch_fuse_chunked": [vp, vp, i32, i32, i32, i64, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32],
         "mistitch_mip": [vp, vp, i32, i64, i64, vp],
         "mistitch_pyramid": [vp, vp, i32, i32, i32, i32, C.POINTER(vp)],
+        "mistitch_pyramid_chunked": [vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp)],
         "mistitch_chunk_layout": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "mistitch_bitshuffle": [vp, vp, vp, i64, i32, i64],
         "mistitch_synchronize": [vp],

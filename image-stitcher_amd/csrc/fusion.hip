@@ -493,6 +493,23 @@ __device__ __forceinline__ Px8 blend_group(int y, int x, int cnt, const int (&ci
   }
 }
 
+// Destination geometry of a mosaic that is born in chunk order (mistitch_fuse_chunked): plane p, row y, column x
+// goes to element ((p * ncy + y / chunk_h) * ncx + x / chunk_w) * chunk_h * chunk_w + (y % chunk_h) * chunk_w +
+// x % chunk_w, and the part of the last chunks beyond the mosaic (rows Hm .. ncy * chunk_h, columns Wm .. ncx * chunk_w)
+// is written as zeros.  chunk_w is a multiple of 8 and the array 16-byte aligned, so an 8-pixel group that starts at a
+// multiple of 8 is an aligned 16 bytes inside one chunk row.  chunk_h == 0: a plain row-major mosaic.
+struct ChunkGeom {
+  int chunk_h, chunk_w, ncy, ncx;
+  __device__ __forceinline__ bool on() const { return chunk_h != 0; }
+  __device__ __forceinline__ int Hp() const { return ncy * chunk_h; }
+  __device__ __forceinline__ int Wp() const { return ncx * chunk_w; }
+  __device__ __forceinline__ int64_t plane_elems() const { return (int64_t)ncy * ncx * chunk_h * chunk_w; }
+  __device__ __forceinline__ int64_t row_base(int y) const {  // of row y inside its plane, chunk column 0
+    return ((int64_t)(y / chunk_h) * ncx * chunk_h + y % chunk_h) * chunk_w;
+  }
+  __device__ __forceinline__ int col_off(int x) const { return (x / chunk_w) * chunk_h * chunk_w + x % chunk_w; }
+};
+
 // Work of one block.  1-D grid of 8 * gx * ceil(gy * n_planes / 8) workgroups with
 // gx = ceil(ceil((Wm + 7) / 8) / (64 GX)) and gy = ceil((row1 - row0) / kBH).
 // GX = 16-byte groups per lane along a row: a wave moves GX KiB of one mosaic row per step.
@@ -510,7 +527,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
                                            const void* __restrict__ flatfields,
                                            const int32_t* __restrict__ tile_ff, const int32_t* __restrict__ bins,
                                            uint16_t* __restrict__ mosaic, int Hm, int Wm, int row0, int row1, int gx,
-                                           int gy, int n_planes, int64_t idle_off, int64_t idle_foff) {
+                                           int gy, int n_planes, int64_t idle_off, int64_t idle_foff, const ChunkGeom cg) {
   constexpr int kQueue = kBH * 64 * GX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) queue_len[0] = queue_len[1] = 0;
@@ -543,8 +560,13 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
   const bool overflow = total > kMaxCand;
   const bool generic_only = overflow || W < 8 || Wm < 8;
   const int ncand = overflow ? n_tiles : total;
-  uint16_t* mplane = mosaic + (int64_t)plane * Hm * Wm;
+  const bool chunked = cg.on();
+  uint16_t* mplane = mosaic + (chunked ? (int64_t)plane * cg.plane_elems() : (int64_t)plane * Hm * Wm);
+  const int Wp = chunked ? cg.Wp() : Wm;  // columns that are written
   const int w_idx = bx * (64 * GX) + lane;  // first aligned group of this lane within a row
+  int col_off[GX];  // chunk order: where the lane's groups lie inside a chunk row (they start at multiples of 8)
+#pragma unroll
+  for (int r = 0; r < GX; ++r) col_off[r] = chunked ? cg.col_off(min(8 * w_idx + 512 * r, Wp - 8)) : 0;
   constexpr size_t ffsize = FF == MISTITCH_FF_F64 ? 8 : 4;
 
   // One mosaic row per wave and step.  The tiles whose rows include y are found once
@@ -574,9 +596,17 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
     const int kk = it < half ? 2 * it : 2 * (it - half) + 1;  // even steps first, then the odd ones
     const int y = y0 + wave + kk * kWaves;
     if (y >= y1) continue;  // wave-uniform
-    uint16_t* rowp = mplane + (int64_t)y * Wm;
-    const int a = (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
+    uint16_t* rowp = mplane + (chunked ? cg.row_base(y) : (int64_t)y * Wm);
+    const int a = chunked ? 0 : (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
     const int64_t yW = (int64_t)y * W;
+    if (y >= Hm) {  // (chunk order) a row of the last chunks below the mosaic: zeros, whatever tiles stick out that far
+#pragma unroll
+      for (int r = 0; r < GX; ++r) {
+        const int x = 8 * w_idx + 512 * r;
+        if (x < Wp) store_px8_stream(rowp + col_off[r], Px8{{0u, 0u, 0u, 0u}});
+      }
+      continue;  // wave-uniform; the cached classification still describes the last mosaic row this wave took
+    }
     unsigned ymask = 0, edges = 0;
     if (!generic_only) {
       const int ly_mine = y - list[lane & (kMaxCand - 1)].ty;
@@ -621,11 +651,12 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
 #pragma unroll
       for (int r = 0; r < GX; ++r) {
         const int x = x0 + 512 * r;
-        const bool outside = !((unsigned)(x + 7) < (unsigned)(Wm + 7));
+        const bool outside = !((unsigned)(x + 7) < (unsigned)(Wp + 7));
         const bool inside = (unsigned)x <= (unsigned)(Wm - 8);  // not cut by the mosaic edge
         const bool copy = MODE == MISTITCH_FUSE_OVERWRITE ? !last_bad[r] : (cnt[r] == 1) & !bad[r];
         int k = (cnt[r] == 0) ? 0 : (copy ? 1 : 2);
         k = (!inside | generic_only) ? 2 : k;
+        k = x >= Wm ? 0 : k;  // (chunk order) the columns of the last chunks beyond the mosaic: zeros
         k = outside ? 3 : k;
         kinds |= (unsigned)k << (2 * r);
         csel |= (idx[r] & 31u) << (5 * r);
@@ -673,14 +704,15 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
     for (int r = 0; r < GX; ++r) {
       const unsigned k = (kinds >> (2 * r)) & 3u;
       const int x = x0 + 512 * r;
+      uint16_t* dst = rowp + (chunked ? col_off[r] : x);
       if (k == 1) {
         if constexpr (FF == MISTITCH_FF_NONE)
-          store_px8_stream(rowp + x, v[r]);
+          store_px8_stream(dst, v[r]);
         else
-          store_px8_stream(rowp + x, corrected8_packed<FF, SAFE>(v[r], f32[FF == MISTITCH_FF_F32 ? r : 0],
-                                                                  f64[FF == MISTITCH_FF_F64 ? r : 0]));
+          store_px8_stream(dst, corrected8_packed<FF, SAFE>(v[r], f32[FF == MISTITCH_FF_F32 ? r : 0],
+                                                            f64[FF == MISTITCH_FF_F64 ? r : 0]));
       } else if (k == 0) {
-        store_px8_stream(rowp + x, Px8{{0u, 0u, 0u, 0u}});
+        store_px8_stream(dst, Px8{{0u, 0u, 0u, 0u}});
       } else if (k == 2) {
         // queued for the whole workgroup: these groups cluster in the overlap bands, and
         // handled in place they would stall every wave that owns a few
@@ -698,8 +730,8 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
     for (unsigned i = tid; i < n_blend; i += kFuseThreads) {
       const unsigned e = queue[i];
       const int y = y0 + (int)((e >> 8) & 31u);
-      uint16_t* rowp = mplane + (int64_t)y * Wm;
-      const int a = (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
+      uint16_t* rowp = mplane + (chunked ? cg.row_base(y) : (int64_t)y * Wm);
+      const int a = chunked ? 0 : (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
       const int x = 8 * (bx * (64 * GX) + (int)(e & 0xffu)) - a;
       const int cnt = (int)((e >> 13) & 3u) + 1;
       const unsigned f = e >> 15;
@@ -714,21 +746,22 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
         ci[2] = (int)((f >> (4 * (cnt - 3))) & 15u);
         ci[3] = cnt == 4 ? (int)(f & 15u) : ci[0];
       }
-      store_px8_stream(rowp + x, blend_group<MODE, FF, SAFE>(y, x, cnt, ci, list, tiles, H, W, flatfields));
+      store_px8_stream(rowp + (chunked ? cg.col_off(x) : x), blend_group<MODE, FF, SAFE>(y, x, cnt, ci, list, tiles, H, W, flatfields));
     }
   }
   const unsigned n_generic = queue_len[1];
   for (unsigned i = tid; i < n_generic; i += kFuseThreads) {
     const unsigned e = queue[kQueue - 1 - i];
     const int y = y0 + (int)((e >> 8) & 31u);
-    uint16_t* rowp = mplane + (int64_t)y * Wm;
-    const int a = (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
+    uint16_t* rowp = mplane + (chunked ? cg.row_base(y) : (int64_t)y * Wm);
+    const int a = chunked ? 0 : (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
     const int x = 8 * (bx * (64 * GX) + (int)(e & 0xffu)) - a;
     const unsigned vm = (((1u << min(8, Wm - x)) - 1u) & ~((1u << max(0, -x)) - 1u)) & 0xffu;
     uint16_t px[8];
     resolve_window<MODE, FF>(y, x, vm, list, ncand, overflow, plane, tiles, H, W, tile_pitch, tile_yx, tile_plane,
                              flatfields, tile_ff, px);
-    store_window(rowp + x, px, vm);
+    // chunk order: the whole group is written, zeros (as resolve_window leaves them) beyond the mosaic's last column
+    store_window(rowp + (chunked ? cg.col_off(x) : x), px, chunked ? 0xffu : vm);
   }
 }
 
@@ -745,7 +778,7 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
                                                        const int32_t* __restrict__ ff_safe,
                                                        uint16_t* __restrict__ mosaic, int Hm, int Wm, int row0,
                                                        int row1, int gx, int gy, int n_planes, int64_t idle_off,
-                                                       int64_t idle_foff) {
+                                                       int64_t idle_foff, const ChunkGeom cg) {
   __shared__ TileRef list[kMaxCand];
   __shared__ unsigned queue[kBH * 64 * GX];
   __shared__ unsigned queue_len[3];  // blend entries, pixel-by-pixel entries, candidates with a flatfield plane
@@ -753,12 +786,12 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
     if (*ff_safe) {
       fuse_block<MODE, FF, GX, true>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
                                      flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes, idle_off,
-                                     idle_foff);
+                                     idle_foff, cg);
       return;
     }
   }
   fuse_block<MODE, FF, GX, false>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
-                                  flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff);
+                                  flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff, cg);
 }
 
 // Are all float32 flatfield values that this call uses finite and within [2^-16, 2^16]?
@@ -869,13 +902,18 @@ struct PyrLevels {
   double* out[kPyrMaxLevels];  // [l]: level l (index 0 unused)
 };
 
+// `cg`: the image is an array of chunks (ChunkGeom, chunk_w a multiple of 8) instead of row-major planes.
 __global__ __launch_bounds__(256) void k_pyramid(const uint16_t* __restrict__ image, int H, int W, int n_levels,
-                                                 PyrLevels lv) {
+                                                 PyrLevels lv, const ChunkGeom cg) {
   __shared__ unsigned sums[2][kPyrTileH / 2][kPyrTileW / 2 + 1];  // ping-pong block sums of the current level
   const int tid = threadIdx.x;
   const int plane = blockIdx.z;
   const int y0 = blockIdx.y * kPyrTileH, x0 = blockIdx.x * kPyrTileW;
-  const uint16_t* img = image + (int64_t)plane * H * W;
+  const bool chunked = cg.on();
+  const uint16_t* img = image + (chunked ? (int64_t)plane * cg.plane_elems() : (int64_t)plane * H * W);
+  auto at = [&](int yy, int xx) -> const uint16_t* {  // pixel (yy, xx) of the plane; xx a multiple of 8 stays inside a chunk row
+    return chunked ? img + cg.row_base(yy) + cg.col_off(xx) : img + (int64_t)yy * W + xx;
+  };
   // level 1: thread (j, g) sums rows 2j, 2j+1 of the 8-pixel group g; 32 x 32 such cells per tile, 4 per thread
   for (int cell = tid; cell < (kPyrTileH / 2) * (kPyrTileW / 8); cell += 256) {
     const int j = cell / (kPyrTileW / 8), g = cell - j * (kPyrTileW / 8);
@@ -884,12 +922,12 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint16_t* __restrict__ im
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if (y + r < H && x + 8 <= W) {
-        const Px8 v = *reinterpret_cast<const Px8*>(img + (int64_t)(y + r) * W + x);
+        const Px8 v = *reinterpret_cast<const Px8*>(at(y + r, x));
 #pragma unroll
         for (int i = 0; i < 8; ++i) px[r][i] = v.at(i);
       } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) px[r][i] = (y + r < H && x + i < W) ? img[(int64_t)(y + r) * W + x + i] : 0u;
+        for (int i = 0; i < 8; ++i) px[r][i] = (y + r < H && x + i < W) ? at(y + r, x)[i] : 0u;
       }
     }
     const int H1 = H >> 1, W1 = W >> 1;
@@ -926,12 +964,12 @@ template <int MODE, int FF, int GX>
 static void launch_fuse(mistitch_ctx* ctx, dim3 grid, const uint16_t* tiles, int n_tiles, int H, int W, int64_t pitch,
                         const int32_t* yx, const int32_t* plane, const void* ffs, const int32_t* tff,
                         const int32_t* bins, const int32_t* ff_safe, uint16_t* mosaic, int Hm, int Wm, int row0,
-                        int row1, int64_t idle_off, int64_t idle_foff) {
+                        int row1, int64_t idle_off, int64_t idle_foff, const ChunkGeom& cg) {
   const int gx = (int)grid.x, gy = (int)grid.y, n_planes = (int)grid.z;
   const unsigned n_wg = 8u * gx * (unsigned)((gy * n_planes + 7) / 8);
   MS_LAUNCH(ctx, MODE == MISTITCH_FUSE_OVERWRITE ? "k_fuse_overwrite" : "k_fuse_feather", (k_fuse<MODE, FF, GX>),
             dim3(n_wg), dim3(kFuseThreads), 0, tiles, n_tiles, H, W, pitch, yx, plane, ffs, tff, bins, ff_safe, mosaic,
-            Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff);
+            Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff, cg);
 }
 
 }  // namespace mistitch
@@ -965,7 +1003,7 @@ int fuse_static_setup(int device) {
 static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w, int64_t tile_pitch,
                      const int32_t* tile_yx, const int32_t* tile_plane, const void* flatfields, int ff_type,
                      const int32_t* tile_ff, uint16_t* mosaic, int n_planes, int mosaic_h, int mosaic_w, int row0,
-                     int row1, int mode, void* static_ws) {
+                     int row1, int mode, void* static_ws, int chunk_h = 0, int chunk_w = 0) {
   MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
   MS_REQUIRE(mosaic, MISTITCH_ERR_ARG, "mosaic is NULL");
   MS_REQUIRE(n_tiles >= 0 && n_planes > 0 && mosaic_h > 0 && mosaic_w > 0, MISTITCH_ERR_ARG, "bad mosaic geometry");
@@ -980,15 +1018,44 @@ static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int 
     MS_REQUIRE(flatfields && tile_ff, MISTITCH_ERR_ARG, "flatfield type given without flatfields / tile_ff");
   if (row1 == row0) return MISTITCH_OK;
   MS_HIP(hipSetDevice(ctx->device));
+  // chunk order: the mosaic is an array of whole chunks; rows below the mosaic in the last chunks belong to the band that
+  // holds the mosaic's last row, columns beyond its last column to every band
+  ChunkGeom cg{0, 0, 0, 0};
+  int out_w = mosaic_w, row_end = row1;
+  if (chunk_h != 0) {
+    MS_REQUIRE(chunk_h > 0 && chunk_w > 0 && chunk_w % 8 == 0, MISTITCH_ERR_UNSUPPORTED,
+               "chunks of %d x %d: the chunk width must be a multiple of 8 pixels (lay the mosaic out with mistitch_chunk_layout instead)",
+               chunk_h, chunk_w);
+    MS_REQUIRE((reinterpret_cast<uintptr_t>(mosaic) & 15u) == 0, MISTITCH_ERR_ARG, "the chunk array is not 16-byte aligned");
+    cg = ChunkGeom{chunk_h, chunk_w, (mosaic_h + chunk_h - 1) / chunk_h, (mosaic_w + chunk_w - 1) / chunk_w};
+    MS_REQUIRE((int64_t)cg.ncx * chunk_h * chunk_w < (1ll << 31) && (int64_t)cg.ncy * chunk_h < (1ll << 31) &&
+                   (int64_t)cg.ncx * chunk_w < (1ll << 31),
+               MISTITCH_ERR_UNSUPPORTED, "a row of chunks of 2^31 elements or more");
+    out_w = cg.ncx * chunk_w;
+    if (row1 == mosaic_h) row_end = cg.ncy * chunk_h;
+  }
   if (n_tiles == 0) {
     // no tile reaches the band: it is what the reference's zero-initialised output array holds (stitcher.py:154-181);
     // the fusion kernels, whose idle lanes read the first tile's pixels, are not launched on an empty tile array
+    if (chunk_h != 0) {  // the rows of the band inside every chunk of a chunk row are contiguous, chunk by chunk
+      const size_t chunk_bytes = (size_t)chunk_h * chunk_w * sizeof(uint16_t);
+      for (int cy = row0 / chunk_h; cy * chunk_h < row_end; ++cy) {
+        const int ra = std::max(row0, cy * chunk_h) - cy * chunk_h, rb = std::min(row_end, (cy + 1) * chunk_h) - cy * chunk_h;
+        for (int pl = 0; pl < n_planes; ++pl)
+          MS_HIP(hipMemset2DAsync(mosaic + (((int64_t)pl * cg.ncy + cy) * cg.ncx * chunk_h + ra) * chunk_w, chunk_bytes, 0,
+                                  (size_t)(rb - ra) * chunk_w * sizeof(uint16_t), (size_t)cg.ncx, ctx->stream));
+      }
+      return MISTITCH_OK;
+    }
     MS_HIP(hipMemset2DAsync(mosaic + (int64_t)row0 * mosaic_w, (size_t)mosaic_h * mosaic_w * sizeof(uint16_t), 0,
                             (size_t)(row1 - row0) * mosaic_w * sizeof(uint16_t), (size_t)n_planes, ctx->stream));
     return MISTITCH_OK;
   }
   const int GX = ff_type == MISTITCH_FF_NONE ? kGxPlain : kGxFlat;
-  const dim3 grid(((mosaic_w + 7 + 7) / 8 + 64 * GX - 1) / (64 * GX), (row1 - row0 + kBH - 1) / kBH, n_planes);
+  // groups per row: plain mosaics count them from the aligned address at or below the row start (up to 7 elements
+  // before it), chunk order from column 0
+  const int groups_per_row = chunk_h != 0 ? out_w / 8 : (mosaic_w + 7 + 7) / 8;
+  const dim3 grid((groups_per_row + 64 * GX - 1) / (64 * GX), (row_end - row0 + kBH - 1) / kBH, n_planes);
   MS_REQUIRE((int64_t)grid.x * grid.y * grid.z < (1ll << 30), MISTITCH_ERR_UNSUPPORTED, "mosaic too large for one launch");
   const int64_t n_blocks = (int64_t)grid.x * grid.y * grid.z;
   int rc;
@@ -1011,7 +1078,7 @@ static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int 
   const int64_t n_bin_groups = (int64_t)grid.x * ((grid.y + kBinRows - 1) / kBinRows) * grid.z;
   MS_LAUNCH(ctx, "k_fuse_bins", k_fuse_bins, dim3((unsigned)((n_bin_groups + 3) / 4)), dim3(256), 0, n_tiles, tile_h, tile_w,
             tile_yx, tile_plane, reinterpret_cast<int32_t*>(ws), (int)grid.x, (int)grid.y, n_planes, mosaic_w,
-            row0, row1, 512 * GX, ff_safe);
+            row0, row_end, 512 * GX, ff_safe);
   if (ff_type == MISTITCH_FF_F32 && n_tiles > 0)
     MS_LAUNCH(ctx, "k_ff_check", k_ff_check, dim3(kFfChunks, kFfPlanes), dim3(256), 0,
               reinterpret_cast<const float*>(flatfields), tile_ff, n_tiles, (int64_t)tile_h * tile_w, ff_safe);
@@ -1030,7 +1097,7 @@ static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int 
   }
 #define MS_FUSE(M, F)                                                                                          \
   launch_fuse<M, F, (F == MISTITCH_FF_NONE ? kGxPlain : kGxFlat)>(ctx, grid, tiles, n_tiles, tile_h, tile_w, tile_pitch, tile_yx, tile_plane, flatfields, tile_ff, \
-                    bins, ff_safe, mosaic, mosaic_h, mosaic_w, row0, row1, idle_off, idle_foff)
+                    bins, ff_safe, mosaic, mosaic_h, mosaic_w, row0, row_end, idle_off, idle_foff, cg)
   if (mode == MISTITCH_FUSE_OVERWRITE) {
     if (ff_type == MISTITCH_FF_NONE) MS_FUSE(MISTITCH_FUSE_OVERWRITE, MISTITCH_FF_NONE);
     else if (ff_type == MISTITCH_FF_F32) MS_FUSE(MISTITCH_FUSE_OVERWRITE, MISTITCH_FF_F32);
@@ -1051,6 +1118,16 @@ extern "C" int mistitch_fuse(mistitch_ctx* ctx, const uint16_t* tiles, int n_til
                              int n_planes, int mosaic_h, int mosaic_w, int row0, int row1, int mode) {
   return fuse_impl(ctx, tiles, n_tiles, tile_h, tile_w, tile_pitch, tile_yx, tile_plane, flatfields, ff_type, tile_ff,
                    mosaic, n_planes, mosaic_h, mosaic_w, row0, row1, mode, nullptr);
+}
+
+extern "C" int mistitch_fuse_chunked(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
+                                     int64_t tile_pitch, const int32_t* tile_yx, const int32_t* tile_plane,
+                                     const void* flatfields, int ff_type, const int32_t* tile_ff, uint16_t* chunks,
+                                     int n_planes, int mosaic_h, int mosaic_w, int chunk_h, int chunk_w, int row0, int row1,
+                                     int mode) {
+  MS_REQUIRE(chunk_h > 0 && chunk_w > 0, MISTITCH_ERR_ARG, "bad chunk shape %d x %d", chunk_h, chunk_w);
+  return fuse_impl(ctx, tiles, n_tiles, tile_h, tile_w, tile_pitch, tile_yx, tile_plane, flatfields, ff_type, tile_ff,
+                   chunks, n_planes, mosaic_h, mosaic_w, row0, row1, mode, nullptr, chunk_h, chunk_w);
 }
 
 extern "C" int mistitch_fuse_static(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
@@ -1104,8 +1181,8 @@ extern "C" int mistitch_apply_flatfield(mistitch_ctx* ctx, const uint16_t* in, c
   return MISTITCH_OK;
 }
 
-extern "C" int mistitch_pyramid(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int h, int w, int n_levels,
-                                double* const* levels) {
+static int pyramid_impl(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int h, int w, int n_levels,
+                        double* const* levels, int chunk_h, int chunk_w) {
   MS_REQUIRE(ctx && image && levels, MISTITCH_ERR_ARG, "NULL argument");
   MS_REQUIRE(n_planes > 0 && h > 0 && w > 0, MISTITCH_ERR_ARG, "bad geometry");
   MS_REQUIRE(n_levels >= 1 && n_levels <= kPyrMaxLevels, MISTITCH_ERR_UNSUPPORTED, "n_levels must be in [1, %d]",
@@ -1119,9 +1196,27 @@ extern "C" int mistitch_pyramid(mistitch_ctx* ctx, const uint16_t* image, int n_
   MS_HIP(hipSetDevice(ctx->device));
   const dim3 grid((w + kPyrTileW - 1) / kPyrTileW, (h + kPyrTileH - 1) / kPyrTileH, n_planes);
   MS_REQUIRE(grid.y < 65536 && grid.z < 65536, MISTITCH_ERR_UNSUPPORTED, "image too large for one launch");
-  MS_LAUNCH(ctx, "k_pyramid", k_pyramid, grid, dim3(256), 0, image, h, w, n_levels, lv);
+  ChunkGeom cg{0, 0, 0, 0};
+  if (chunk_h != 0) {
+    MS_REQUIRE(chunk_h > 0 && chunk_w > 0 && chunk_w % 8 == 0, MISTITCH_ERR_UNSUPPORTED,
+               "chunks of %d x %d: the chunk width must be a multiple of 8 pixels", chunk_h, chunk_w);
+    cg = ChunkGeom{chunk_h, chunk_w, (h + chunk_h - 1) / chunk_h, (w + chunk_w - 1) / chunk_w};
+    MS_REQUIRE((int64_t)cg.ncx * chunk_h * chunk_w < (1ll << 31), MISTITCH_ERR_UNSUPPORTED, "a row of chunks of 2^31 elements or more");
+  }
+  MS_LAUNCH(ctx, "k_pyramid", k_pyramid, grid, dim3(256), 0, image, h, w, n_levels, lv, cg);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
+}
+
+extern "C" int mistitch_pyramid(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int h, int w, int n_levels,
+                                double* const* levels) {
+  return pyramid_impl(ctx, image, n_planes, h, w, n_levels, levels, 0, 0);
+}
+
+extern "C" int mistitch_pyramid_chunked(mistitch_ctx* ctx, const uint16_t* chunks, int n_planes, int h, int w, int chunk_h,
+                                        int chunk_w, int n_levels, double* const* levels) {
+  MS_REQUIRE(chunk_h > 0 && chunk_w > 0, MISTITCH_ERR_ARG, "bad chunk shape %d x %d", chunk_h, chunk_w);
+  return pyramid_impl(ctx, chunks, n_planes, h, w, n_levels, levels, chunk_h, chunk_w);
 }
 
 // ---- chunk layout for the array writer ---------------------------------------------------------

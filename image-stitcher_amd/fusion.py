@@ -112,15 +112,35 @@ def compute_mip(tiles):
     return out.cpu().numpy() if is_np else out
 
 
-def generate_pyramid(image, num_levels: int):
+def generate_pyramid(image, num_levels: int, chunked_hw: Optional[Tuple[int, int]] = None):
     """[image, level 1, ..., level num_levels-1] as Stitcher.generate_pyramid builds it
     (stitcher.py:652-668): level l is the float64 mean over 2^l x 2^l blocks of the two
-    last axes, excess rows / columns trimmed.  ``image`` is uint16 with any leading axes."""
+    last axes, excess rows / columns trimmed.  ``image`` is uint16 with any leading axes.
+    ``chunked_hw`` = (h, w): ``image`` is a mosaic born in chunk order, ``[..., ncy, ncx, chunk_h, chunk_w]`` of an
+    h x w mosaic (``fuse_tiles(chunks=...)``); the levels come out as row-major planes all the same."""
     import ctypes as C
 
     torch = _torch()
     is_np = not isinstance(image, torch.Tensor)
     img = to_device_u16(image)
+    if chunked_hw is not None:
+        if img.dim() < 4:
+            raise ValueError("a chunk-ordered mosaic has the axes [..., ncy, ncx, chunk_h, chunk_w]")
+        h, w = int(chunked_hw[0]), int(chunked_hw[1])
+        ncy, ncx, ch, cw = (int(v) for v in img.shape[-4:])
+        if (ncy, ncx) != (-(-h // ch), -(-w // cw)):
+            raise ValueError(f"{ncy} x {ncx} chunks of {ch} x {cw} do not hold a {h} x {w} mosaic")
+        lead = tuple(int(v) for v in img.shape[:-4])
+        planes = int(np.prod(lead)) if lead else 1
+        levels = [torch.empty(lead + (h >> l, w >> l), dtype=torch.float64, device=img.device)
+                  for l in range(1, int(num_levels))]
+        arr = (C.c_void_p * max(int(num_levels), 1))()
+        for l, t in enumerate(levels, start=1):
+            arr[l] = t.data_ptr() if t.numel() else None
+        check(lib.mistitch_pyramid_chunked(_lib.default_context().handle, ptr(img.contiguous()), planes, h, w, ch, cw,
+                                           int(num_levels), arr))
+        out = [img] + levels
+        return [t.cpu().numpy() for t in out] if is_np else out
     if img.dim() < 2:
         raise ValueError("image must have at least two axes")
     lead = tuple(int(v) for v in img.shape[:-2])
@@ -139,7 +159,8 @@ def generate_pyramid(image, num_levels: int):
 
 def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_w: int,
                flatfields=None, tile_ff=None, mode: str = "overwrite", rows: Optional[Tuple[int, int]] = None,
-               out=None, ctx: Optional[_lib.Context] = None, static_workspace: bool = False):
+               out=None, ctx: Optional[_lib.Context] = None, static_workspace: bool = False,
+               chunks: Optional[Tuple[int, int]] = None):
     """Fuse tiles (given IN PLACEMENT ORDER) into ``[n_planes, mosaic_h, mosaic_w]`` uint16.
 
     tiles      [T, H, W] uint16 (CUDA tensor, or NumPy array that is uploaded)
@@ -149,6 +170,11 @@ def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_
     rows       (row0, row1): only this band of every plane is written (multi-GPU sharding)
     static_workspace  call ``mistitch_fuse_static``: no device allocation inside the library
                       (``out`` should then be given too); fails beyond its size limit
+    chunks     (chunk_h, chunk_w): the mosaic is born in the chunk order of the array writer
+               (``mistitch_fuse_chunked``): the result is ``[n_planes, ncy, ncx, chunk_h, chunk_w]``, every
+               ``[cy, cx]`` one whole zero-padded chunk of a Zarr array with chunks ``(1, 1, 1, chunk_h, chunk_w)``
+               (parameters.py:695-701), the same bytes as ``omezarr.chunk_layout`` of the plain mosaic;
+               chunk_w must be a multiple of 8
     """
     torch = _torch()
     tiles = to_device_u16(tiles)
@@ -173,12 +199,26 @@ def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_
             raise ValueError("tile_ff is required with flatfields")
         tff = torch.as_tensor(np.asarray(tile_ff, dtype=np.int32).reshape(-1) if not isinstance(tile_ff, torch.Tensor)
                               else tile_ff).to(device=dev, dtype=torch.int32).contiguous()
-    if out is None:
-        alloc = torch.zeros if rows is not None else torch.empty
-        out = alloc((n_planes, mosaic_h, mosaic_w), dtype=torch.int16, device=dev).view(torch.uint16)
     row0, row1 = (0, mosaic_h) if rows is None else (int(rows[0]), int(rows[1]))
     mode_id = {"overwrite": FUSE_OVERWRITE, "feather": FUSE_FEATHER}[mode]
     ctx = ctx or _lib.default_context()
+    if chunks is not None:
+        if static_workspace:
+            raise ValueError("the chunk-ordered mosaic has no allocation-free entry point")
+        ch, cw = int(chunks[0]), int(chunks[1])
+        shape = (n_planes, -(-mosaic_h // ch), -(-mosaic_w // cw), ch, cw)
+        if out is None:
+            alloc = torch.zeros if rows is not None else torch.empty
+            out = alloc(shape, dtype=torch.int16, device=dev).view(torch.uint16)
+        elif tuple(out.shape) != shape:
+            raise ValueError(f"out must be {shape}, got {tuple(out.shape)}")
+        check(lib.mistitch_fuse_chunked(ctx.handle, ptr(tiles), n_tiles, h, w, h * w, ptr(yx), ptr(pl), ptr(ff), _ff_type(ff),
+                                        ptr(tff), ptr(out), int(n_planes), int(mosaic_h), int(mosaic_w), ch, cw, row0, row1,
+                                        mode_id))
+        return out
+    if out is None:
+        alloc = torch.zeros if rows is not None else torch.empty
+        out = alloc((n_planes, mosaic_h, mosaic_w), dtype=torch.int16, device=dev).view(torch.uint16)
     entry = lib.mistitch_fuse_static if static_workspace else lib.mistitch_fuse
     check(entry(ctx.handle, ptr(tiles), n_tiles, h, w, h * w, ptr(yx), ptr(pl), ptr(ff), _ff_type(ff),
                 ptr(tff), ptr(out), int(n_planes), int(mosaic_h), int(mosaic_w), row0, row1, mode_id))

@@ -146,22 +146,31 @@ def iter_chunks(level_chunks, n_c: int, n_z: int) -> Iterator[Tuple[Tuple[int, i
 
 def write_ome_zarr(path: str, mosaic, channel_names: Sequence[str], channel_colors: Sequence[int], px_um: float,
                    tile_h: int, tile_w: int, n_levels: Optional[int] = None, dz_um: float = 1.0, name: str = "region_t0",
-                   ctx=None, writers: int = 8) -> Dict[str, object]:
+                   ctx=None, writers: int = 8, chunked_hw: Optional[Tuple[int, int]] = None) -> Dict[str, object]:
     """Write ``mosaic`` [C, Z, H, W] uint16 (device) as the OME-Zarr the reference saves for one region
     and timepoint (arrays "0" .. "n_levels-1" of shape (1, C, Z, H >> l, W >> l), level 0 uint16 and
-    the others float64 block means, uncompressed).  Returns {"levels": [...shapes], "chunks": (...)}."""
+    the others float64 block means, uncompressed).  Returns {"levels": [...shapes], "chunks": (...)}.
+    ``chunked_hw`` = (H, W): ``mosaic`` was born in chunk order, [C, Z, ncy, ncx, chunk_h, chunk_w] with the
+    reference's chunk shape for these tiles (``fusion.fuse_tiles(chunks=reference_chunks(tile_h, tile_w)[3:])``):
+    level 0 goes to the files as it is, without a layout pass."""
     torch = _torch()
     from . import fusion
-    if mosaic.dim() != 4:
-        raise ValueError("mosaic must be [C, Z, H, W]")
-    n_c, n_z, h, w = (int(v) for v in mosaic.shape)
-    if len(channel_names) != n_c or len(channel_colors) != n_c:
-        raise ValueError("one name and one colour per channel")
     chunks = reference_chunks(tile_h, tile_w)
     ch, cw = chunks[3], chunks[4]
+    if chunked_hw is not None:
+        if mosaic.dim() != 6 or tuple(int(v) for v in mosaic.shape[-2:]) != (ch, cw):
+            raise ValueError(f"a chunk-ordered mosaic must be [C, Z, ncy, ncx, {ch}, {cw}]")
+        n_c, n_z = int(mosaic.shape[0]), int(mosaic.shape[1])
+        h, w = int(chunked_hw[0]), int(chunked_hw[1])
+    else:
+        if mosaic.dim() != 4:
+            raise ValueError("mosaic must be [C, Z, H, W]")
+        n_c, n_z, h, w = (int(v) for v in mosaic.shape)
+    if len(channel_names) != n_c or len(channel_colors) != n_c:
+        raise ValueError("one name and one colour per channel")
     if n_levels is None:
         n_levels = default_pyramid_levels(w, h)
-    levels = fusion.generate_pyramid(mosaic, n_levels)     # [mosaic, float64 means ...] on the device
+    levels = fusion.generate_pyramid(mosaic, n_levels, chunked_hw=chunked_hw)   # [mosaic, float64 means ...] on the device
     os.makedirs(path, exist_ok=True)
     with open(os.path.join(path, ".zgroup"), "w") as f:
         json.dump({"zarr_format": 2}, f)
@@ -175,7 +184,8 @@ def write_ome_zarr(path: str, mosaic, channel_names: Sequence[str], channel_colo
         pool = ThreadPoolExecutor(max_workers=writers)
     try:
         for l, level in enumerate(levels):
-            lh, lw = int(level.shape[-2]), int(level.shape[-1])
+            born_chunked = l == 0 and chunked_hw is not None
+            lh, lw = (h, w) if born_chunked else (int(level.shape[-2]), int(level.shape[-1]))
             shape = (1, n_c, n_z, lh, lw)
             shapes.append(shape)
             root = os.path.join(path, str(l))
@@ -190,7 +200,7 @@ def write_ome_zarr(path: str, mosaic, channel_names: Sequence[str], channel_colo
             jobs = []
             for c in range(n_c):
                 for z in range(n_z):
-                    laid = chunk_layout(level[c, z], ch, cw, ctx=ctx)
+                    laid = level[c, z].unsqueeze(0) if born_chunked else chunk_layout(level[c, z], ch, cw, ctx=ctx)
                     host = (laid.view(torch.int16) if laid.dtype == torch.uint16 else laid).cpu().numpy().view(np_dtype)
                     for j in jobs:
                         j.result()

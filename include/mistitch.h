@@ -284,6 +284,22 @@ int mistitch_fuse_static(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, 
                          const void* flatfields, int ff_type, const int32_t* tile_ff, uint16_t* mosaic,
                          int n_planes, int mosaic_h, int mosaic_w, int row0, int row1, int mode);
 
+/* mistitch_fuse with the mosaic born in the chunk order of the array writer: `chunks` is
+ * [n_planes][ncy][ncx][chunk_h][chunk_w] uint16 with ncy = ceil(mosaic_h / chunk_h), ncx = ceil(mosaic_w / chunk_w),
+ * every [cy][cx] one whole C-ordered chunk of a Zarr array with chunks (1, 1, 1, chunk_h, chunk_w) (the reference's
+ * chunk shape is one tile, parameters.py:695-701), zero where it sticks out of the mosaic: the bytes
+ * mistitch_chunk_layout makes of the plain mosaic, without writing and re-reading that mosaic.  Replaces the tile loop
+ * of Stitcher.stitch_region (stitcher.py:388-405) together with the rechunking that da.store does on the host for
+ * save_region_ome_zarr (stitcher.py:575-594).  Rows [row0, row1) of the mosaic are written; the band that reaches
+ * mosaic_h also writes the zero rows below it in the last chunks.  chunk_w must be a multiple of 8 and `chunks`
+ * 16-byte aligned (MISTITCH_ERR_UNSUPPORTED / _ARG otherwise: fuse plainly and call mistitch_chunk_layout).
+ * All other arguments as mistitch_fuse.                                                                          */
+int mistitch_fuse_chunked(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int tile_h, int tile_w,
+                          int64_t tile_pitch, const int32_t* tile_yx, const int32_t* tile_plane,
+                          const void* flatfields, int ff_type, const int32_t* tile_ff, uint16_t* chunks,
+                          int n_planes, int mosaic_h, int mosaic_w, int chunk_h, int chunk_w, int row0, int row1,
+                          int mode);
+
 /* Per-pixel maximum over `n` images of h*w uint16 (image i at in + i*pitch).
  * Replaces Stitcher.compute_mip (stitcher.py:102-121).                           */
 int mistitch_mip(mistitch_ctx* ctx, const uint16_t* in, int n, int64_t pitch, int64_t n_pixels,
@@ -297,6 +313,12 @@ int mistitch_mip(mistitch_ctx* ctx, const uint16_t* in, int n, int64_t pitch, in
  * (stitcher.py:652-668), whose levels are float64 too.  n_levels <= 7.            */
 int mistitch_pyramid(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int h, int w,
                      int n_levels, double* const* levels);
+
+/* mistitch_pyramid of a mosaic that was born in chunk order (mistitch_fuse_chunked): `chunks` is
+ * [n_planes][ceil(h / chunk_h)][ceil(w / chunk_w)][chunk_h][chunk_w]; the levels come out as mistitch_pyramid's,
+ * row-major planes of float64.  chunk_w must be a multiple of 8.                                          */
+int mistitch_pyramid_chunked(mistitch_ctx* ctx, const uint16_t* chunks, int n_planes, int h, int w, int chunk_h,
+                             int chunk_w, int n_levels, double* const* levels);
 
 /* The planes of an image, [n_planes][h][w] of uint16 (elem_size 2) or float64 (elem_size 8:
  * the pyramid levels), laid out as the chunks a Zarr array with chunks (1, 1, 1, chunk_h,

@@ -145,3 +145,27 @@ def test_bitshuffle_of_a_laid_out_chunk():
     chunk = laid[0, 1, 1]
     got = omezarr.bitshuffle(chunk, 2, 1 << 14).cpu().numpy()
     assert np.array_equal(got, omezarr.bitshuffle_numpy(_np_chunks(img, 128, 256)[0, 1, 1], 2, 1 << 14))
+
+
+@pytest.mark.gpu
+def test_store_of_a_mosaic_born_in_chunk_order_equals_the_plain_one(tmp_path):
+    """fuse_tiles(chunks=...) -> write_ome_zarr(chunked_hw=...) writes the files that the plain mosaic gives: level 0
+    without a layout pass, the pyramid read from the chunk-ordered mosaic."""
+    import filecmp
+    import torch
+    from image_stitcher_amd import fusion
+    from tests.fusion_cases import overlapping_scene
+    tiles, yx, plane, mh, mw = overlapping_scene(21, 3, 3, 128, 256, n_planes=2, jitter=3, overlap=0.1)
+    plain = fusion.fuse_tiles(tiles, yx, plane, 2, mh, mw, mode="feather").reshape(2, 1, mh, mw)
+    born = fusion.fuse_tiles(tiles, yx, plane, 2, mh, mw, mode="feather", chunks=(128, 256))
+    born = born.reshape(2, 1, *born.shape[1:])
+    a, b = str(tmp_path / "plain.zarr"), str(tmp_path / "born.zarr")
+    kw = dict(channel_names=["a", "b"], channel_colors=[1, 2], px_um=0.5, tile_h=128, tile_w=256, n_levels=3)
+    omezarr.write_ome_zarr(a, plain, **kw)
+    omezarr.write_ome_zarr(b, born, chunked_hw=(mh, mw), **kw)
+    for level in range(3):
+        la, lb = omezarr.read_level(a, level), omezarr.read_level(b, level)
+        assert la.shape == lb.shape and np.array_equal(la, lb)
+    cmp = filecmp.dircmp(a, b)
+    assert not cmp.left_only and not cmp.right_only
+    assert filecmp.cmp(os.path.join(a, "0", "0", "1", "0", "1", "1"), os.path.join(b, "0", "0", "1", "0", "1", "1"), shallow=False)

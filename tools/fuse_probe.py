@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--only", default="", help="run one variant only, e.g. feather:f32")
     ap.add_argument("--kernels", action="store_true", help="per-kernel milliseconds of one more call")
     ap.add_argument("--align", type=int, default=1, help="round tile columns down to a multiple of this")
+    ap.add_argument("--chunks", action="store_true",
+                    help="also time the mosaic born in chunk order (chunks of one tile) and the chunk layout of the plain one")
     args = ap.parse_args()
     import torch
     from image_stitcher_amd import _lib, synth
@@ -60,6 +62,25 @@ def main():
             feather_bytes = ch * (2 * n * t * t + 2 * mh * mw)
             print(f"{mode_name:9s} ff={ff_name:4s} {ms:8.3f} ms  {feather_bytes / ms / 1e6:8.1f} GB/s (2B*tile px + 2B*out px)",
                   flush=True)
+            if args.chunks:
+                ncy, ncx = -(-mh // t), -(-mw // t)
+                laid = torch.empty((ch, ncy, ncx, t, t), dtype=torch.int16, device=dev).view(torch.uint16)
+                def run_chunked():
+                    check(lib.mistitch_fuse_chunked(ctx.handle, ptr(tiles), ch * n, t, t, t * t, ptr(d_yx), ptr(d_plane), ptr(ffs),
+                                                    fft, ptr(d_plane) if ffs is not None else ptr(None), ptr(laid), ch, mh, mw,
+                                                    t, t, 0, mh, mode))
+                def run_layout():
+                    check(lib.mistitch_chunk_layout(ctx.handle, ptr(mosaic), 2, ch, mh, mw, t, t, ptr(laid)))
+                for label, fn in (("born in chunk order", run_chunked), ("chunk layout of the plain mosaic", run_layout)):
+                    fn()
+                    torch.cuda.synchronize()
+                    e0.record()
+                    for _ in range(args.reps):
+                        fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    print(f"   {label}: {e0.elapsed_time(e1) / args.reps:.3f} ms", flush=True)
+                del laid
             if args.kernels:
                 ctx.profile(True)
                 run()
