@@ -36,7 +36,7 @@ EXPORTS = [
     "mistitch_profile_enable", "mistitch_profile_collect", "mistitch_subpixel_shift",
     "mistitch_set_upsample_factor", "mistitch_pyramid", "mistitch_chunk_layout", "mistitch_refine_pairs",
     "mistitch_register_pairs_flatfield", "mistitch_fuse_static", "mistitch_register_pairs_candidates",
-    "mistitch_bitshuffle", "mistitch_fuse_chunked", "mistitch_pyramid_chunked",
+    "mistitch_bitshuffle", "mistitch_fuse_chunked", "mistitch_pyramid_chunked", "mistitch_set_pixel_max",
 ]
 
 
@@ -70,6 +70,7 @@ def _load() -> C.CDLL:
         "mistitch_ncc": [vp, vp, i64, vp, i64, i32, i32, i32, vp],
         "mistitch_subpixel_shift": [vp, vp, i64, vp, i64, i32, i32, u32, i32, vp],
         "mistitch_set_upsample_factor": [vp, i32],
+        "mistitch_set_pixel_max": [vp, i32],
         "mistitch_edge_variance": [vp, vp, i64, i32, i32, vp],
         "mistitch_apply_flatfield": [vp, vp, vp, i32, vp, i32, i32, i32],
         "mistitch_fuse": [vp, vp, i32, i32, i32, i64, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32],
@@ -134,6 +135,20 @@ class Context:
 
     def set_upsample_factor(self, u: int) -> None:
         check(lib.mistitch_set_upsample_factor(self.handle, int(u)))
+
+    def pixel_max(self, value: int):
+        """``with ctx.pixel_max(255): ...``: calls inside clip flatfield-corrected pixels to ``value`` (8-bit tiles);
+        back to 65535 afterwards."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            check(lib.mistitch_set_pixel_max(self.handle, int(value)))
+            try:
+                yield self
+            finally:
+                check(lib.mistitch_set_pixel_max(self.handle, 65535))
+        return scope()
 
     def synchronize(self) -> None:
         check(lib.mistitch_synchronize(self.handle))

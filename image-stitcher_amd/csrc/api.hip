@@ -56,6 +56,13 @@ extern "C" int mistitch_set_staging_limit(mistitch_ctx* ctx, int64_t bytes) {
   return MISTITCH_OK;
 }
 
+extern "C" int mistitch_set_pixel_max(mistitch_ctx* ctx, int pixel_max) {
+  MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
+  MS_REQUIRE(pixel_max >= 1 && pixel_max <= 65535, MISTITCH_ERR_ARG, "pixel_max must be within 1 .. 65535");
+  ctx->pixel_max = pixel_max;
+  return MISTITCH_OK;
+}
+
 extern "C" int mistitch_synchronize(mistitch_ctx* ctx) {
   MS_REQUIRE(ctx, MISTITCH_ERR_ARG, "ctx is NULL");
   MS_HIP(hipSetDevice(ctx->device));

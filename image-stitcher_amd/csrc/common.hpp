@@ -152,6 +152,7 @@ struct mistitch_ctx {
   int pair_chunk = 128;  // pairs processed per pipeline pass (bounds the FFT workspace)
   int64_t staging_limit = 4ll << 30;  // strips of all pairs of a call are staged at once up to this many bytes
   int upsample_factor = 100;  // subpixel grid: 1 / upsample_factor pixels
+  int pixel_max = 65535;      // largest value of the tiles' pixel type: what a flatfield-corrected pixel is clipped to
   std::map<long long, mistitch::FftPlanHost> plans;  // key = n * 2 + (is_f64)
   mistitch::DevBuf desc, staging, spectrum, slabs, partial, peaks, cand, acc, misc, bins, flags, ups;
   std::vector<char> host_scratch;

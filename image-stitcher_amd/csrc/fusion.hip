@@ -88,14 +88,14 @@ __device__ __forceinline__ TileRef make_ref(int t, const int32_t* __restrict__ t
 }
 
 template <int FF>
-__device__ __forceinline__ uint16_t flatfield_one(uint16_t v, const void* ffrow, int i) {
+__device__ __forceinline__ uint16_t flatfield_one(uint16_t v, const void* ffrow, int i, unsigned vmax) {
   if constexpr (FF == MISTITCH_FF_F32) {
     float q = MS_FDIV((float)v, reinterpret_cast<const float*>(ffrow)[i]);
-    q = fminf(fmaxf(q, 0.0f), 65535.0f);
+    q = fminf(fmaxf(q, 0.0f), (float)vmax);
     return (uint16_t)(unsigned int)q;
   } else if constexpr (FF == MISTITCH_FF_F64) {
     double q = (double)v / reinterpret_cast<const double*>(ffrow)[i];
-    q = fmin(fmax(q, 0.0), 65535.0);
+    q = fmin(fmax(q, 0.0), (double)vmax);
     return (uint16_t)(unsigned int)q;
   } else {
     return v;
@@ -105,7 +105,8 @@ __device__ __forceinline__ uint16_t flatfield_one(uint16_t v, const void* ffrow,
 // Fetch the pixels of `m` (bit i = window pixel i) from tile row `src` (points
 // at window pixel 0, which may lie outside the tile when bit 0 is clear).
 template <int FF>
-__device__ __forceinline__ void fetch_window(const uint16_t* src, const void* ffrow, unsigned m, uint16_t (&px)[8]) {
+__device__ __forceinline__ void fetch_window(const uint16_t* src, const void* ffrow, unsigned m, uint16_t (&px)[8],
+                                             unsigned vmax) {
   if (m == 0xffu) {
     const Px8 v = *reinterpret_cast<const Px8*>(src);
     if constexpr (FF == MISTITCH_FF_F32) {
@@ -113,7 +114,7 @@ __device__ __forceinline__ void fetch_window(const uint16_t* src, const void* ff
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float q = MS_FDIV((float)v.at(i), f.v[i]);
-        q = fminf(fmaxf(q, 0.0f), 65535.0f);
+        q = fminf(fmaxf(q, 0.0f), (float)vmax);
         px[i] = (uint16_t)(unsigned int)q;
       }
     } else if constexpr (FF == MISTITCH_FF_F64) {
@@ -121,7 +122,7 @@ __device__ __forceinline__ void fetch_window(const uint16_t* src, const void* ff
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         double q = (double)v.at(i) / f.v[i];
-        q = fmin(fmax(q, 0.0), 65535.0);
+        q = fmin(fmax(q, 0.0), (double)vmax);
         px[i] = (uint16_t)(unsigned int)q;
       }
     } else {
@@ -131,7 +132,7 @@ __device__ __forceinline__ void fetch_window(const uint16_t* src, const void* ff
   } else {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (m & (1u << i)) px[i] = flatfield_one<FF>(src[i], ffrow, i);
+      if (m & (1u << i)) px[i] = flatfield_one<FF>(src[i], ffrow, i, vmax);
   }
 }
 
@@ -221,7 +222,7 @@ __device__ __forceinline__ void resolve_window(int y, int x, unsigned valid, con
                                                int W, int64_t tile_pitch, const int32_t* __restrict__ tile_yx,
                                                const int32_t* __restrict__ tile_plane,
                                                const void* __restrict__ flatfields,
-                                               const int32_t* __restrict__ tile_ff, uint16_t (&px)[8]) {
+                                               const int32_t* __restrict__ tile_ff, uint16_t (&px)[8], unsigned vmax) {
   constexpr size_t ffsize = FF == MISTITCH_FF_F64 ? 8 : 4;
 #pragma unroll
   for (int i = 0; i < 8; ++i) px[i] = 0;
@@ -246,9 +247,9 @@ __device__ __forceinline__ void resolve_window(int y, int x, unsigned valid, con
       if (FF != MISTITCH_FF_NONE && c.ff >= 0) {
         const char* ffrow =
             reinterpret_cast<const char*>(flatfields) + (((int64_t)c.ff * H + ly) * W + lx0) * (int64_t)ffsize;
-        fetch_window<FF>(src, ffrow, m, px);
+        fetch_window<FF>(src, ffrow, m, px, vmax);
       } else {
-        fetch_window<MISTITCH_FF_NONE>(src, nullptr, m, px);
+        fetch_window<MISTITCH_FF_NONE>(src, nullptr, m, px, vmax);
       }
       todo &= ~m;
     }
@@ -279,9 +280,9 @@ __device__ __forceinline__ void resolve_window(int y, int x, unsigned valid, con
       if (FF != MISTITCH_FF_NONE && c.ff >= 0) {
         const char* ffrow =
             reinterpret_cast<const char*>(flatfields) + (((int64_t)c.ff * H + ly) * W + lx0) * (int64_t)ffsize;
-        fetch_window<FF>(src, ffrow, m, v);
+        fetch_window<FF>(src, ffrow, m, v, vmax);
       } else {
-        fetch_window<MISTITCH_FF_NONE>(src, nullptr, m, v);
+        fetch_window<MISTITCH_FF_NONE>(src, nullptr, m, v, vmax);
       }
       const float wy = (float)min(ly + 1, H - ly);
       ++n_touch;
@@ -349,7 +350,7 @@ __device__ __forceinline__ f2 div2_u16(f2 n, f2 d) {
 // [0, 65535].  SAFE: every flatfield value is known to be finite and within
 // [2^-16, 2^16] (checked once per call by k_ff_check), which admits div2_u16.
 template <int FF, bool SAFE>
-__device__ __forceinline__ void corrected8(const Px8& v, const F8& f32, const D8& f64, unsigned (&out)[8]) {
+__device__ __forceinline__ void corrected8(const Px8& v, const F8& f32, const D8& f64, unsigned (&out)[8], unsigned vmax) {
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const unsigned d = v.d[p];
@@ -357,15 +358,15 @@ __device__ __forceinline__ void corrected8(const Px8& v, const F8& f32, const D8
       const f2 n = {(float)(d & 0xffffu), (float)(d >> 16)};
       if constexpr (SAFE) {
         const f2 q = div2_u16(n, f2{f32.v[2 * p], f32.v[2 * p + 1]});  // positive; saturated when packed or below
-        out[2 * p] = min((unsigned int)q.x, 65535u);
-        out[2 * p + 1] = min((unsigned int)q.y, 65535u);
+        out[2 * p] = min((unsigned int)q.x, vmax);
+        out[2 * p + 1] = min((unsigned int)q.y, vmax);
       } else {
-        out[2 * p] = (unsigned int)fminf(fmaxf(MS_FDIV(n.x, f32.v[2 * p]), 0.0f), 65535.0f);
-        out[2 * p + 1] = (unsigned int)fminf(fmaxf(MS_FDIV(n.y, f32.v[2 * p + 1]), 0.0f), 65535.0f);
+        out[2 * p] = (unsigned int)fminf(fmaxf(MS_FDIV(n.x, f32.v[2 * p]), 0.0f), (float)vmax);
+        out[2 * p + 1] = (unsigned int)fminf(fmaxf(MS_FDIV(n.y, f32.v[2 * p + 1]), 0.0f), (float)vmax);
       }
     } else if constexpr (FF == MISTITCH_FF_F64) {
-      out[2 * p] = (unsigned int)fmin(fmax((double)(d & 0xffffu) / f64.v[2 * p], 0.0), 65535.0);
-      out[2 * p + 1] = (unsigned int)fmin(fmax((double)(d >> 16) / f64.v[2 * p + 1], 0.0), 65535.0);
+      out[2 * p] = (unsigned int)fmin(fmax((double)(d & 0xffffu) / f64.v[2 * p], 0.0), (double)vmax);
+      out[2 * p + 1] = (unsigned int)fmin(fmax((double)(d >> 16) / f64.v[2 * p + 1], 0.0), (double)vmax);
     } else {
       out[2 * p] = d & 0xffffu;
       out[2 * p + 1] = d >> 16;
@@ -381,20 +382,23 @@ __device__ __forceinline__ unsigned pack2(unsigned lo, unsigned hi) {
 }
 
 template <int FF, bool SAFE>
-__device__ __forceinline__ Px8 corrected8_packed(const Px8& v, const F8& f32, const D8& f64) {
+__device__ __forceinline__ Px8 corrected8_packed(const Px8& v, const F8& f32, const D8& f64, unsigned vmax) {
   if constexpr (FF == MISTITCH_FF_F32 && SAFE) {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const us2 top = {(unsigned short)vmax, (unsigned short)vmax};  // the pixel type's largest value (one v_pk_min_u16 per dword)
     Px8 o;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const unsigned d = v.d[p];
       const f2 n = {(float)(d & 0xffffu), (float)(d >> 16)};
       const f2 q = div2_u16(n, f2{f32.v[2 * p], f32.v[2 * p + 1]});
-      o.d[p] = pack2((unsigned int)q.x, (unsigned int)q.y);
+      o.d[p] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(
+                   __builtin_bit_cast(us2, pack2((unsigned int)q.x, (unsigned int)q.y)), top));
     }
     return o;
   } else {
     unsigned u[8];
-    corrected8<FF, SAFE>(v, f32, f64, u);
+    corrected8<FF, SAFE>(v, f32, f64, u, vmax);
     Px8 o;
 #pragma unroll
     for (int p = 0; p < 4; ++p) o.d[p] = u[2 * p] | (u[2 * p + 1] << 16);
@@ -414,7 +418,7 @@ __device__ __forceinline__ Px8 corrected8_packed(const Px8& v, const F8& f32, co
 template <int MODE, int FF, bool SAFE>
 __device__ __forceinline__ Px8 blend_group(int y, int x, int cnt, const int (&ci)[4], const TileRef* list,
                                            const uint16_t* __restrict__ tiles, int H, int W,
-                                           const void* __restrict__ flatfields) {
+                                           const void* __restrict__ flatfields, unsigned vmax) {
   constexpr size_t ffsize = FF == MISTITCH_FF_F64 ? 8 : 4;
   Px8 sv[4];
   F8 sf32[FF == MISTITCH_FF_F32 ? 4 : 1];
@@ -443,7 +447,7 @@ __device__ __forceinline__ Px8 blend_group(int y, int x, int cnt, const int (&ci
     for (int i = 0; i < 8; ++i) out[i] = 0u;
     auto put = [&](int q) {
       unsigned u[8];
-      corrected8<FF, SAFE>(sv[q], sf32[FF == MISTITCH_FF_F32 ? q : 0], sf64[FF == MISTITCH_FF_F64 ? q : 0], u);
+      corrected8<FF, SAFE>(sv[q], sf32[FF == MISTITCH_FF_F32 ? q : 0], sf64[FF == MISTITCH_FF_F64 ? q : 0], u, vmax);
 #pragma unroll
       for (int i = 0; i < 8; ++i) out[i] = (unsigned)(lxs[q] + i) < (unsigned)W ? u[i] : out[i];
     };
@@ -465,7 +469,7 @@ __device__ __forceinline__ Px8 blend_group(int y, int x, int cnt, const int (&ci
       const float wy = (float)min(lys[q] + 1, H - lys[q]);
       const float a = (float)(lxs[q] + 1), b = (float)(W - lxs[q]);  // ramp from the left / right tile edge
       unsigned u[8];
-      corrected8<FF, SAFE>(sv[q], sf32[FF == MISTITCH_FF_F32 ? q : 0], sf64[FF == MISTITCH_FF_F64 ? q : 0], u);
+      corrected8<FF, SAFE>(sv[q], sf32[FF == MISTITCH_FF_F32 ? q : 0], sf64[FF == MISTITCH_FF_F64 ? q : 0], u, vmax);
 #pragma unroll
       for (int p = 0; p < 4; ++p) {
         const f2 val = {(float)u[2 * p], (float)u[2 * p + 1]};
@@ -527,7 +531,8 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
                                            const void* __restrict__ flatfields,
                                            const int32_t* __restrict__ tile_ff, const int32_t* __restrict__ bins,
                                            uint16_t* __restrict__ mosaic, int Hm, int Wm, int row0, int row1, int gx,
-                                           int gy, int n_planes, int64_t idle_off, int64_t idle_foff, const ChunkGeom cg) {
+                                           int gy, int n_planes, int64_t idle_off, int64_t idle_foff, const ChunkGeom cg,
+                                           unsigned vmax) {
   constexpr int kQueue = kBH * 64 * GX;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) queue_len[0] = queue_len[1] = 0;
@@ -710,7 +715,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
           store_px8_stream(dst, v[r]);
         else
           store_px8_stream(dst, corrected8_packed<FF, SAFE>(v[r], f32[FF == MISTITCH_FF_F32 ? r : 0],
-                                                            f64[FF == MISTITCH_FF_F64 ? r : 0]));
+                                                            f64[FF == MISTITCH_FF_F64 ? r : 0], vmax));
       } else if (k == 0) {
         store_px8_stream(dst, Px8{{0u, 0u, 0u, 0u}});
       } else if (k == 2) {
@@ -746,7 +751,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
         ci[2] = (int)((f >> (4 * (cnt - 3))) & 15u);
         ci[3] = cnt == 4 ? (int)(f & 15u) : ci[0];
       }
-      store_px8_stream(rowp + (chunked ? cg.col_off(x) : x), blend_group<MODE, FF, SAFE>(y, x, cnt, ci, list, tiles, H, W, flatfields));
+      store_px8_stream(rowp + (chunked ? cg.col_off(x) : x), blend_group<MODE, FF, SAFE>(y, x, cnt, ci, list, tiles, H, W, flatfields, vmax));
     }
   }
   const unsigned n_generic = queue_len[1];
@@ -759,7 +764,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
     const unsigned vm = (((1u << min(8, Wm - x)) - 1u) & ~((1u << max(0, -x)) - 1u)) & 0xffu;
     uint16_t px[8];
     resolve_window<MODE, FF>(y, x, vm, list, ncand, overflow, plane, tiles, H, W, tile_pitch, tile_yx, tile_plane,
-                             flatfields, tile_ff, px);
+                             flatfields, tile_ff, px, vmax);
     // chunk order: the whole group is written, zeros (as resolve_window leaves them) beyond the mosaic's last column
     store_window(rowp + (chunked ? cg.col_off(x) : x), px, chunked ? 0xffu : vm);
   }
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
                                                        const int32_t* __restrict__ ff_safe,
                                                        uint16_t* __restrict__ mosaic, int Hm, int Wm, int row0,
                                                        int row1, int gx, int gy, int n_planes, int64_t idle_off,
-                                                       int64_t idle_foff, const ChunkGeom cg) {
+                                                       int64_t idle_foff, const ChunkGeom cg, unsigned vmax) {
   __shared__ TileRef list[kMaxCand];
   __shared__ unsigned queue[kBH * 64 * GX];
   __shared__ unsigned queue_len[3];  // blend entries, pixel-by-pixel entries, candidates with a flatfield plane
@@ -786,12 +791,12 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
     if (*ff_safe) {
       fuse_block<MODE, FF, GX, true>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
                                      flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes, idle_off,
-                                     idle_foff, cg);
+                                     idle_foff, cg, vmax);
       return;
     }
   }
   fuse_block<MODE, FF, GX, false>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
-                                  flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff, cg);
+                                  flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff, cg, vmax);
 }
 
 // Are all float32 flatfield values that this call uses finite and within [2^-16, 2^16]?
@@ -839,7 +844,7 @@ __global__ __launch_bounds__(256) void k_ff_check(const float* __restrict__ flat
 template <int FF>
 __global__ __launch_bounds__(256) void k_flatfield(const uint16_t* in, const void* __restrict__ ff, uint16_t* out,
                                                    int64_t n_px_per_tile, unsigned bpt, unsigned tile0,
-                                                   const int32_t* __restrict__ ff_safe) {
+                                                   const int32_t* __restrict__ ff_safe, unsigned vmax) {
   const unsigned t = tile0 + blockIdx.x / bpt;
   const int64_t q = (int64_t)(blockIdx.x % bpt) * 256 + threadIdx.x;
   if (q >= n_px_per_tile / 8) return;
@@ -850,22 +855,22 @@ __global__ __launch_bounds__(256) void k_flatfield(const uint16_t* in, const voi
   if constexpr (FF == MISTITCH_FF_F64) f64 = *reinterpret_cast<const D8*>(reinterpret_cast<const double*>(ff) + q * 8);
   Px8 o;
   if (FF == MISTITCH_FF_F32 && *ff_safe)
-    o = corrected8_packed<FF, FF == MISTITCH_FF_F32>(v, f32, f64);
+    o = corrected8_packed<FF, FF == MISTITCH_FF_F32>(v, f32, f64, vmax);
   else
-    o = corrected8_packed<FF, false>(v, f32, f64);
+    o = corrected8_packed<FF, false>(v, f32, f64, vmax);
   *reinterpret_cast<Px8*>(out + t * n_px_per_tile + q * 8) = o;
 }
 
 template <int FF>
 __global__ void k_flatfield_tail(const uint16_t* in, const void* ff, uint16_t* out, int64_t n_px_per_tile,
-                                 int n_tiles) {
+                                 int n_tiles, unsigned vmax) {
   const int64_t tail0 = n_px_per_tile / 8 * 8;
   const int ntail = (int)(n_px_per_tile - tail0);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ntail * n_tiles) return;
   const int t = i / ntail, e = i - t * ntail;
   const char* ffrow = reinterpret_cast<const char*>(ff) + tail0 * (FF == MISTITCH_FF_F64 ? 8 : 4);
-  out[t * n_px_per_tile + tail0 + e] = flatfield_one<FF>(in[t * n_px_per_tile + tail0 + e], ffrow, e);
+  out[t * n_px_per_tile + tail0 + e] = flatfield_one<FF>(in[t * n_px_per_tile + tail0 + e], ffrow, e, vmax);
 }
 
 // Per-pixel maximum over n images.
@@ -969,7 +974,7 @@ static void launch_fuse(mistitch_ctx* ctx, dim3 grid, const uint16_t* tiles, int
   const unsigned n_wg = 8u * gx * (unsigned)((gy * n_planes + 7) / 8);
   MS_LAUNCH(ctx, MODE == MISTITCH_FUSE_OVERWRITE ? "k_fuse_overwrite" : "k_fuse_feather", (k_fuse<MODE, FF, GX>),
             dim3(n_wg), dim3(kFuseThreads), 0, tiles, n_tiles, H, W, pitch, yx, plane, ffs, tff, bins, ff_safe, mosaic,
-            Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff, cg);
+            Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff, cg, (unsigned)ctx->pixel_max);
 }
 
 }  // namespace mistitch
@@ -1167,15 +1172,15 @@ extern "C" int mistitch_apply_flatfield(mistitch_ctx* ctx, const uint16_t* in, c
   for (unsigned t0 = 0; gpt && t0 < (unsigned)n_tiles; t0 += tiles_per_launch) {
     const unsigned nt = std::min(tiles_per_launch, (unsigned)n_tiles - t0);
     if (ff_type == MISTITCH_FF_F32)
-      MS_LAUNCH(ctx, "k_flatfield", k_flatfield<MISTITCH_FF_F32>, dim3(nt * bpt), dim3(256), 0, in, flatfield, out, npx, bpt, t0, ff_safe);
+      MS_LAUNCH(ctx, "k_flatfield", k_flatfield<MISTITCH_FF_F32>, dim3(nt * bpt), dim3(256), 0, in, flatfield, out, npx, bpt, t0, ff_safe, (unsigned)ctx->pixel_max);
     else
-      MS_LAUNCH(ctx, "k_flatfield", k_flatfield<MISTITCH_FF_F64>, dim3(nt * bpt), dim3(256), 0, in, flatfield, out, npx, bpt, t0, ff_safe);
+      MS_LAUNCH(ctx, "k_flatfield", k_flatfield<MISTITCH_FF_F64>, dim3(nt * bpt), dim3(256), 0, in, flatfield, out, npx, bpt, t0, ff_safe, (unsigned)ctx->pixel_max);
   }
   if (ntail) {
     if (ff_type == MISTITCH_FF_F32)
-      MS_LAUNCH(ctx, "k_flatfield_tail", k_flatfield_tail<MISTITCH_FF_F32>, dim3((ntail + 63) / 64), dim3(64), 0, in, flatfield, out, npx, n_tiles);
+      MS_LAUNCH(ctx, "k_flatfield_tail", k_flatfield_tail<MISTITCH_FF_F32>, dim3((ntail + 63) / 64), dim3(64), 0, in, flatfield, out, npx, n_tiles, (unsigned)ctx->pixel_max);
     else
-      MS_LAUNCH(ctx, "k_flatfield_tail", k_flatfield_tail<MISTITCH_FF_F64>, dim3((ntail + 63) / 64), dim3(64), 0, in, flatfield, out, npx, n_tiles);
+      MS_LAUNCH(ctx, "k_flatfield_tail", k_flatfield_tail<MISTITCH_FF_F64>, dim3((ntail + 63) / 64), dim3(64), 0, in, flatfield, out, npx, n_tiles, (unsigned)ctx->pixel_max);
   }
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;

@@ -449,13 +449,13 @@ __global__ __launch_bounds__(256) void k_transpose_strips64(const uint16_t* tile
 
 // trunc(clip(v / ff)) for one pixel (tile_registration.py:2142-2181); FF as in mistitch.h.
 template <int FF>
-__device__ __forceinline__ unsigned ff_corrected(unsigned v, const void* ff, int64_t idx) {
+__device__ __forceinline__ unsigned ff_corrected(unsigned v, const void* ff, int64_t idx, unsigned vmax) {
   if constexpr (FF == MISTITCH_FF_F32) {
     const float q = __fdiv_rn((float)v, reinterpret_cast<const float*>(ff)[idx]);
-    return (unsigned)fminf(fmaxf(q, 0.0f), 65535.0f);
+    return (unsigned)fminf(fmaxf(q, 0.0f), (float)vmax);
   } else {
     const double q = (double)v / reinterpret_cast<const double*>(ff)[idx];
-    return (unsigned)fmin(fmax(q, 0.0), 65535.0);
+    return (unsigned)fmin(fmax(q, 0.0), (double)vmax);
   }
 }
 
@@ -470,7 +470,7 @@ template <int FF, bool EDGE>
 __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, int64_t tile_pitch, int H, int W,
                                                         int w_left, int w_top, const int32_t* pair_idx,
                                                         const PairDesc* desc, const int8_t* status, int pair0,
-                                                        const void* __restrict__ ff) {
+                                                        const void* __restrict__ ff, unsigned vmax) {
   __shared__ uint16_t tile[64][64 + 2];
   const int p = pair0 + (blockIdx.z >> 1), which = blockIdx.z & 1;
   if (status[p] != MISTITCH_PAIR_OK) return;
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, i
       for (int i = 0; i < 16; ++i) {
         const int r = (t >> 6) + 4 * i;
         const int64_t at = (int64_t)(l0 + r) * W + x0 + c;
-        tile[r][c] = s0 + c < d.S ? (uint16_t)ff_corrected<FF>(img[at], ff, at) : (uint16_t)0;
+        tile[r][c] = s0 + c < d.S ? (uint16_t)ff_corrected<FF>(img[at], ff, at, vmax) : (uint16_t)0;
       }
     } else {
 #pragma unroll
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, i
         unsigned* dstw = reinterpret_cast<unsigned*>(&tile[row + 32 * i][8 * sub]);  // rows are 132 bytes: 4-byte aligned
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          dstw[q] = ff_corrected<FF>(w4[q] & 0xffffu, ff, at + 2 * q) | (ff_corrected<FF>(w4[q] >> 16, ff, at + 2 * q + 1) << 16);
+          dstw[q] = ff_corrected<FF>(w4[q] & 0xffffu, ff, at + 2 * q, vmax) | (ff_corrected<FF>(w4[q] >> 16, ff, at + 2 * q + 1, vmax) << 16);
       }
     }
     __syncthreads();
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, i
       unsigned r4[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q)
-        r4[q] = ff_corrected<FF>(w4[q] & 0xffffu, ff, at + 2 * q) | (ff_corrected<FF>(w4[q] >> 16, ff, at + 2 * q + 1) << 16);
+        r4[q] = ff_corrected<FF>(w4[q] & 0xffffu, ff, at + 2 * q, vmax) | (ff_corrected<FF>(w4[q] >> 16, ff, at + 2 * q + 1, vmax) << 16);
       o.x = r4[0];
       o.y = r4[1];
       o.z = r4[2];
@@ -548,7 +548,7 @@ template <int FF>
 __global__ __launch_bounds__(256) void k_stage_strips_any(const uint16_t* tiles, int64_t tile_pitch, int H, int W,
                                                           int w_left, int w_top, const int32_t* pair_idx,
                                                           const PairDesc* desc, const int8_t* status, int pair0,
-                                                          const void* __restrict__ ff) {
+                                                          const void* __restrict__ ff, unsigned vmax) {
   const int p = pair0 + (blockIdx.y >> 1), which = blockIdx.y & 1;
   if (status[p] != MISTITCH_PAIR_OK) return;
   const PairDesc d = desc[p];
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256) void k_stage_strips_any(const uint16_t* tiles,
       x = l;
     }
     const int64_t at = (int64_t)y * W + x;
-    dst[e] = (uint16_t)ff_corrected<FF>(img[at], ff, at);
+    dst[e] = (uint16_t)ff_corrected<FF>(img[at], ff, at, vmax);
   }
 }
 
@@ -4307,7 +4307,7 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
         const dim3 grid(std::max(H, W) / 64, (std::max(w_left, w_top) + 63) / 64, 2 * n);
 #define MS_STAGE(FF, EDGE)                                                                                           \
   MS_LAUNCH(ctx, "k_stage_strips", (k_stage_strips64<FF, EDGE>), grid, dim3(256), 0, tiles, tile_pitch, H, W, w_left, \
-            w_top, pair_idx, ws.desc, status, pair0, ff)
+            w_top, pair_idx, ws.desc, status, pair0, ff, (unsigned)ctx->pixel_max)
         if (ff_type == MISTITCH_FF_F32) {
           if (fast) MS_STAGE(MISTITCH_FF_F32, false);
           else MS_STAGE(MISTITCH_FF_F32, true);
@@ -4320,10 +4320,10 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
         const dim3 grid(256, 2 * n);
         if (ff_type == MISTITCH_FF_F32)
           MS_LAUNCH(ctx, "k_stage_strips", k_stage_strips_any<MISTITCH_FF_F32>, grid, dim3(256), 0, tiles, tile_pitch, H, W,
-                    w_left, w_top, pair_idx, ws.desc, status, pair0, ff);
+                    w_left, w_top, pair_idx, ws.desc, status, pair0, ff, (unsigned)ctx->pixel_max);
         else
           MS_LAUNCH(ctx, "k_stage_strips", k_stage_strips_any<MISTITCH_FF_F64>, grid, dim3(256), 0, tiles, tile_pitch, H, W,
-                    w_left, w_top, pair_idx, ws.desc, status, pair0, ff);
+                    w_left, w_top, pair_idx, ws.desc, status, pair0, ff, (unsigned)ctx->pixel_max);
       }
       MS_LAUNCH(ctx, "k_edge_stats", k_edge_stats_staged, dim3(2, n), dim3(kThreads), 0, ws.desc, status, pair0, 2e3);
     } else if (vec_top && H % 64 == 0 && w_left % 64 == 0) {

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import FF_F32, FF_F64, FF_NONE, FUSE_FEATHER, FUSE_OVERWRITE, check, lib, ptr
-from .registration import to_device_u16
+from .registration import pixel_max_of, to_device_u16
 
 
 def _torch():
@@ -72,23 +72,27 @@ def _to_device_float(arr, device):
 
 # ---- kernels -----------------------------------------------------------------
 def apply_flatfield_to_image(image, flatfield, dtype=None):
-    """``(image / flatfield).clip(0, 65535).astype(uint16)`` on the device
-    (tile_registration.py:2142-2181).  NumPy in -> NumPy out; tensors in -> tensor out.
-    ``image`` may be [H, W] or [N, H, W]; the flatfield plane is shared."""
+    """``(image / flatfield).clip(0, iinfo(dtype).max).astype(dtype)`` on the device
+    (tile_registration.py:2142-2181); ``dtype`` defaults to the image's, uint16 or uint8.  NumPy in -> NumPy out;
+    tensors in -> tensor out.  ``image`` may be [H, W] or [N, H, W]; the flatfield plane is shared."""
     torch = _torch()
     is_np = not isinstance(image, torch.Tensor)
     img_shape = tuple(image.shape)
     if tuple(img_shape[-2:]) != tuple(flatfield.shape) or len(img_shape) not in (2, 3):
         raise ValueError(f"Flatfield shape {tuple(flatfield.shape)} doesn't match image shape {img_shape}")
-    if dtype is not None and np.dtype(dtype) != np.uint16:
-        raise TypeError("only uint16 output is supported")
+    top = pixel_max_of(image) if dtype is None else {np.dtype(np.uint16): 65535, np.dtype(np.uint8): 255}.get(np.dtype(dtype))
+    if top is None:
+        raise TypeError("only uint16 and uint8 output is supported")
     t = to_device_u16(image)
     ff = _to_device_float(flatfield, t.device)
     out = torch.empty(t.shape, dtype=torch.int16, device=t.device).view(torch.uint16)
     n = 1 if t.dim() == 2 else int(t.shape[0])
     h, w = (int(s) for s in t.shape[-2:])
     ctx = _lib.default_context()
-    check(lib.mistitch_apply_flatfield(ctx.handle, ptr(t), ptr(ff), _ff_type(ff), ptr(out), n, h, w))
+    with ctx.pixel_max(top):
+        check(lib.mistitch_apply_flatfield(ctx.handle, ptr(t), ptr(ff), _ff_type(ff), ptr(out), n, h, w))
+    if top == 255:
+        out = out.view(torch.int16).to(torch.uint8)
     return out.cpu().numpy() if is_np else out
 
 
@@ -160,7 +164,7 @@ def generate_pyramid(image, num_levels: int, chunked_hw: Optional[Tuple[int, int
 def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_w: int,
                flatfields=None, tile_ff=None, mode: str = "overwrite", rows: Optional[Tuple[int, int]] = None,
                out=None, ctx: Optional[_lib.Context] = None, static_workspace: bool = False,
-               chunks: Optional[Tuple[int, int]] = None):
+               chunks: Optional[Tuple[int, int]] = None, pixel_max: Optional[int] = None):
     """Fuse tiles (given IN PLACEMENT ORDER) into ``[n_planes, mosaic_h, mosaic_w]`` uint16.
 
     tiles      [T, H, W] uint16 (CUDA tensor, or NumPy array that is uploaded)
@@ -177,6 +181,11 @@ def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_
                chunk_w must be a multiple of 8
     """
     torch = _torch()
+    # 8-bit tiles (or pixel_max=255 for tiles the caller has widened): corrected pixels are clipped to 255 and the mosaic
+    # comes back as uint8, the tile type as in the reference (stitcher.py:154-181, :260-267)
+    top = pixel_max_of(tiles) if pixel_max is None else int(pixel_max)
+    if top == 255 and out is not None:
+        raise ValueError("`out` cannot be given with 8-bit tiles: the kernels write a 16-bit mosaic that is narrowed afterwards")
     tiles = to_device_u16(tiles)
     if tiles.dim() != 3:
         raise ValueError(f"tiles must be [T, H, W], got {tuple(tiles.shape)}")
@@ -212,17 +221,19 @@ def fuse_tiles(tiles, tile_yx, tile_plane, n_planes: int, mosaic_h: int, mosaic_
             out = alloc(shape, dtype=torch.int16, device=dev).view(torch.uint16)
         elif tuple(out.shape) != shape:
             raise ValueError(f"out must be {shape}, got {tuple(out.shape)}")
-        check(lib.mistitch_fuse_chunked(ctx.handle, ptr(tiles), n_tiles, h, w, h * w, ptr(yx), ptr(pl), ptr(ff), _ff_type(ff),
-                                        ptr(tff), ptr(out), int(n_planes), int(mosaic_h), int(mosaic_w), ch, cw, row0, row1,
-                                        mode_id))
-        return out
+        with ctx.pixel_max(top):
+            check(lib.mistitch_fuse_chunked(ctx.handle, ptr(tiles), n_tiles, h, w, h * w, ptr(yx), ptr(pl), ptr(ff), _ff_type(ff),
+                                            ptr(tff), ptr(out), int(n_planes), int(mosaic_h), int(mosaic_w), ch, cw, row0, row1,
+                                            mode_id))
+        return out.view(torch.int16).to(torch.uint8) if top == 255 else out
     if out is None:
         alloc = torch.zeros if rows is not None else torch.empty
         out = alloc((n_planes, mosaic_h, mosaic_w), dtype=torch.int16, device=dev).view(torch.uint16)
     entry = lib.mistitch_fuse_static if static_workspace else lib.mistitch_fuse
-    check(entry(ctx.handle, ptr(tiles), n_tiles, h, w, h * w, ptr(yx), ptr(pl), ptr(ff), _ff_type(ff),
-                ptr(tff), ptr(out), int(n_planes), int(mosaic_h), int(mosaic_w), row0, row1, mode_id))
-    return out
+    with ctx.pixel_max(top):
+        check(entry(ctx.handle, ptr(tiles), n_tiles, h, w, h * w, ptr(yx), ptr(pl), ptr(ff), _ff_type(ff),
+                    ptr(tff), ptr(out), int(n_planes), int(mosaic_h), int(mosaic_w), row0, row1, mode_id))
+    return out.view(torch.int16).to(torch.uint8) if top == 255 else out
 
 
 # ---- the stitch_region tile loop ---------------------------------------------
@@ -287,7 +298,7 @@ def stitch_region(tiles, infos: Sequence[TileInfo], channel_names: Sequence[str]
                   selected_z: Optional[Sequence[int]] = None, mode: str = "overwrite",
                   update_progress: Optional[Callable[[int, int], None]] = None, apply_mip: bool = False):
     """Device replacement of the tile loop of ``Stitcher.stitch_region`` (stitcher.py:313-410):
-    returns the 5-D ``(1, C, Z, H, W)`` uint16 CUDA tensor.
+    returns the 5-D ``(1, C, Z, H, W)`` CUDA tensor of the tiles' type (uint16, or uint8 for 8-bit tiles).
 
     tiles[i] belongs to infos[i]; ``tiles`` is ``[T, H, W]``, ``[T, 1, H, W]`` (squeezed, stitcher.py:241-251)
     or ``[T, H, W, 3]`` RGB, whose colours go to the planes ``{base}_R/_G/_B`` of ``channel_names`` with
@@ -298,6 +309,7 @@ def stitch_region(tiles, infos: Sequence[TileInfo], channel_names: Sequence[str]
     the output then has one z level (stitcher.py:152, 347-385).  ``flatfields`` is keyed by plane index.
     """
     torch = _torch()
+    top = pixel_max_of(tiles)
     tiles = to_device_u16(tiles)
     rgb = tiles.dim() == 4 and int(tiles.shape[-1]) == 3
     if tiles.dim() == 4 and not rgb:
@@ -369,7 +381,7 @@ def stitch_region(tiles, infos: Sequence[TileInfo], channel_names: Sequence[str]
         cidx = plane // n_z
         tff = np.array([keys.index(int(c)) if int(c) in flatfields else -1 for c in cidx], dtype=np.int32)
     mosaic = fuse_tiles(sources.view(torch.uint16), yx, plane, n_c * n_z, height, width, flatfields=ffs, tile_ff=tff,
-                        mode=mode)
+                        mode=mode, pixel_max=top)
     if update_progress is not None:
         for done in progress:
             update_progress(done, total)

@@ -57,20 +57,33 @@ def _fft_flag(fft: str, window: Optional[str] = None) -> int:
     raise ValueError(f"unknown fft precision {fft!r}")
 
 
+def pixel_max_of(arr) -> int:
+    """Largest value of the pixel type of ``arr`` (uint8: 255, uint16: 65535): what the reference clips
+    flatfield-corrected pixels to (``np.iinfo(dtype).max``, tile_registration.py:2177-2180, stitcher.py:260-267)."""
+    torch = _torch()
+    if isinstance(arr, torch.Tensor):
+        return 255 if arr.dtype == torch.uint8 else 65535
+    return 255 if np.asarray(arr).dtype == np.uint8 else 65535
+
+
 def to_device_u16(arr, device=None):
-    """uint16 NumPy array (or tensor) -> contiguous uint16 tensor on the GPU."""
+    """uint16 or uint8 NumPy array (or tensor) -> contiguous uint16 tensor on the GPU.  8-bit tiles (MONO8 cameras;
+    the reference takes the dtype of the first image, parameters.py:685) are widened: every kernel works on 16-bit
+    pixels, and the arithmetic of registration does not depend on the type (float64 transforms, integer moments)."""
     torch = _torch()
     if isinstance(arr, torch.Tensor):
         t = arr
     else:
         a = np.ascontiguousarray(arr)
-        if a.dtype != np.uint16:
-            raise TypeError(f"tiles must be uint16, got {a.dtype}")
+        if a.dtype not in (np.uint16, np.uint8):
+            raise TypeError(f"tiles must be uint16 or uint8, got {a.dtype}")
         t = torch.from_numpy(a)
-    if t.dtype != torch.uint16:
-        raise TypeError(f"tiles must be uint16, got {t.dtype}")
+    if t.dtype not in (torch.uint16, torch.uint8):
+        raise TypeError(f"tiles must be uint16 or uint8, got {t.dtype}")
     if not t.is_cuda:
         t = t.cuda(device)
+    if t.dtype == torch.uint8:
+        t = t.to(torch.int16).view(torch.uint16)
     return t.contiguous()
 
 
@@ -108,6 +121,7 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
     every candidate in evaluation order, NaN ncc where the reference does not score it.
     """
     torch = _torch()
+    pixel_max = pixel_max_of(tiles)
     tiles = to_device_u16(tiles)
     if tiles.dim() != 3:
         raise ValueError(f"tiles must be [N, H, W], got {tuple(tiles.shape)}")
@@ -145,13 +159,15 @@ def register_pairs(tiles, pair_idx, pair_dir, edge_width: int = DEFAULT_EDGE_WID
         ff_type = _lib.FF_F32 if ff.dtype == torch.float32 else _lib.FF_F64
     if return_candidates:
         table = torch.empty((n_pairs, 160 if peaks10 else 32, 3), dtype=torch.float64, device=dev)
-        check(lib.mistitch_register_pairs_candidates(ctx.handle, ptr(tiles), n, h, w, h * w, ptr(ff), ff_type, ptr(pi),
-                                                     ptr(pd_), n_pairs, int(edge_width), flags, ptr(out), ptr(status),
-                                                     ptr(table)))
+        with ctx.pixel_max(pixel_max):
+            check(lib.mistitch_register_pairs_candidates(ctx.handle, ptr(tiles), n, h, w, h * w, ptr(ff), ff_type, ptr(pi),
+                                                         ptr(pd_), n_pairs, int(edge_width), flags, ptr(out), ptr(status),
+                                                         ptr(table)))
         return out, status, table
     if ff is not None:
-        check(lib.mistitch_register_pairs_flatfield(ctx.handle, ptr(tiles), n, h, w, h * w, ptr(ff), ff_type, ptr(pi),
-                                                    ptr(pd_), n_pairs, int(edge_width), flags, ptr(out), ptr(status)))
+        with ctx.pixel_max(pixel_max):   # 8-bit tiles: corrected strips are clipped to 255
+            check(lib.mistitch_register_pairs_flatfield(ctx.handle, ptr(tiles), n, h, w, h * w, ptr(ff), ff_type, ptr(pi),
+                                                        ptr(pd_), n_pairs, int(edge_width), flags, ptr(out), ptr(status)))
         return out, status
     check(lib.mistitch_register_pairs(ctx.handle, ptr(tiles), n, h, w, h * w, ptr(pi), ptr(pd_), n_pairs,
                                       int(edge_width), flags, ptr(out), ptr(status)))

@@ -210,6 +210,12 @@ int mistitch_subpixel_shift(mistitch_ctx* ctx, const uint16_t* strip1, int64_t p
  * (default 100, SubpixelConfig.upsample_factor at tile_registration.py:574). */
 int mistitch_set_upsample_factor(mistitch_ctx* ctx, int upsample_factor);
 
+/* The largest value of the acquisition's pixel type (default 65535).  The reference takes the dtype of the first image
+ * (parameters.py:685) and clips flatfield-corrected pixels to that type's range (stitcher.py:260-267,
+ * tile_registration.py:2177-2180): tiles of an 8-bit camera, widened to uint16 for this library, are corrected with
+ * pixel_max = 255.  Applies to every later call on the context that divides by a flatfield.                       */
+int mistitch_set_pixel_max(mistitch_ctx* ctx, int pixel_max);
+
 /* Peak correlation matrix of two equal-shape uint16 strips.
  * Replaces pcm() (registration/_translation_computation.py:282-340).
  *   strip1/2   h x w uint16 with row pitches pitch1/pitch2 (elements)

@@ -180,10 +180,10 @@ def fuse_feather(tiles: np.ndarray, tile_yx: np.ndarray, tile_plane: Sequence[in
         wv = wt[: y1 - y, : x1 - x]
         num[p, y:y1, x:x1] = num[p, y:y1, x:x1] + wv * tile[: y1 - y, : x1 - x].astype(np.float32)
         den[p, y:y1, x:x1] = den[p, y:y1, x:x1] + wv
-    out = np.zeros((n_planes, mosaic_h, mosaic_w), dtype=np.uint16)
+    out = np.zeros((n_planes, mosaic_h, mosaic_w), dtype=tiles.dtype)   # the tiles' type, as the overwrite mosaic
     covered = den > 0
     q = np.floor(num[covered] / den[covered] + np.float32(0.5))
-    out[covered] = np.minimum(q, np.float32(65535.0)).astype(np.uint16)
+    out[covered] = np.minimum(q, np.float32(np.iinfo(tiles.dtype).max)).astype(tiles.dtype)
     return out
 
 
