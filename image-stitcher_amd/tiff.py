@@ -182,9 +182,8 @@ class TiffFile:
         return nxt
 
     # -- OME ---------------------------------------------------------------------------------------
-    def ome_dims(self) -> Optional[Dict[str, object]]:
-        """SizeC / SizeZ / SizeT and DimensionOrder of the first Image of the OME-XML in the first page's
-        description; None when the file carries none."""
+    def _ome_pixels(self):
+        """The first Pixels element of the OME-XML in the first page's description, or None."""
         desc = self.pages[0].description if self.pages else None
         if not desc or "<OME" not in desc:
             return None
@@ -194,27 +193,75 @@ class TiffFile:
             return None
         for el in root.iter():
             if el.tag.endswith("}Pixels") or el.tag == "Pixels":
-                names = [c.get("Name") or c.get("ID") for c in el if c.tag.endswith("Channel")]
-                return {"C": int(el.get("SizeC", 1)), "Z": int(el.get("SizeZ", 1)), "T": int(el.get("SizeT", 1)),
-                        "order": el.get("DimensionOrder", "XYZCT"), "channel_names": names or None}
+                return el
         return None
 
+    def ome_dims(self) -> Optional[Dict[str, object]]:
+        """SizeC / SizeZ / SizeT and DimensionOrder of the first Image of the OME-XML in the first page's
+        description; None when the file carries none, or sizes that are not positive numbers (the caller then
+        takes the reference's fallback for an OME loader that fails, tile_registration.py:2236-2247)."""
+        el = self._ome_pixels()
+        if el is None:
+            return None
+        names = [c.get("Name") or c.get("ID") for c in el if c.tag.endswith("Channel")]
+        try:
+            dims = {"C": int(el.get("SizeC", 1)), "Z": int(el.get("SizeZ", 1)), "T": int(el.get("SizeT", 1))}
+        except (TypeError, ValueError):
+            return None
+        order = el.get("DimensionOrder", "XYZCT")
+        if min(dims.values()) < 1 or len(order) != 5 or order[:2] != "XY" or sorted(order[2:]) != ["C", "T", "Z"]:
+            return None
+        return dict(dims, order=order, channel_names=names or None)
+
     def ome_page(self, channel: int = 0, z: int = 0, t: int = 0) -> int:
-        """Index of the page that holds (t, channel, z): the planes follow DimensionOrder, its first
-        letter after XY varying fastest (what ``OMETiffLoader.read_slice`` indexes through tifffile's
-        series axes, image_loaders.py:270-316)."""
+        """Index of the page (IFD) that holds (t, channel, z).  The planes are numbered in DimensionOrder, its first
+        letter after XY varying fastest; the TiffData elements of the Pixels element say which IFDs hold which planes
+        (OME-TIFF specification: a block starts at plane (FirstC, FirstZ, FirstT), default 0, covers PlaneCount planes,
+        default 1 when IFD is given and all planes otherwise, and sits at IFD, IFD + 1, ...; default IFD 0).  Without
+        TiffData elements plane k is IFD k.  This is what ``OMETiffLoader.read_slice`` reaches through tifffile's
+        series axes (image_loaders.py:270-316); tifffile is not importable here, so files whose TiffData blocks reorder
+        planes are covered by hand-built cases only (parity with tifffile unpinned).  A plane that a block places in
+        ANOTHER file of a multi-file set (UUID FileName) raises."""
         dims = self.ome_dims()
         if dims is None:
             raise ValueError(f"{self.path}: no OME-XML")
         for name, v in (("channel", (channel, dims["C"])), ("z", (z, dims["Z"])), ("t", (t, dims["T"]))):
             if not 0 <= v[0] < v[1]:
                 raise ValueError(f"{name} {v[0]} out of range [0, {v[1]})")
-        index, stride = 0, 1
-        at = {"C": channel, "Z": z, "T": t}
-        for axis in str(dims["order"])[2:]:
-            index += at[axis] * stride
-            stride *= int(dims[axis])
-        return index
+
+        def plane_number(c_, z_, t_):
+            index, stride = 0, 1
+            at = {"C": c_, "Z": z_, "T": t_}
+            for axis in str(dims["order"])[2:]:
+                index += at[axis] * stride
+                stride *= int(dims[axis])
+            return index
+
+        index = plane_number(channel, z, t)
+        total = dims["C"] * dims["Z"] * dims["T"]
+        blocks = [c for c in self._ome_pixels() if c.tag.endswith("TiffData")]
+        if not blocks:
+            return index
+
+        def num(el, key, default):
+            try:
+                return int(el.get(key, default))
+            except (TypeError, ValueError):
+                raise ValueError(f"{self.path}: TiffData attribute {key}={el.get(key)!r} is not a number")
+
+        for td in blocks:
+            start = plane_number(num(td, "FirstC", 0), num(td, "FirstZ", 0), num(td, "FirstT", 0))
+            count = num(td, "PlaneCount", 1 if td.get("IFD") is not None else total - start)
+            if start <= index < start + count:
+                for child in td:
+                    other = child.get("FileName") if child.tag.endswith("UUID") else None
+                    if other and os.path.basename(other) != os.path.basename(self.path):
+                        raise ValueError(f"{self.path}: plane (c={channel}, z={z}, t={t}) is stored in {other}")
+                ifd = num(td, "IFD", 0) + (index - start)
+                if not 0 <= ifd < len(self.pages):
+                    raise ValueError(f"{self.path}: TiffData points at IFD {ifd} of {len(self.pages)}")
+                return ifd
+        raise ValueError(f"{self.path}: no TiffData block holds plane (c={channel}, z={z}, t={t})")
 
     # -- pixels ------------------------------------------------------------------------------------
     def read_page_into(self, page_index: int, dst: np.ndarray) -> None:

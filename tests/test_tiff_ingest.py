@@ -206,6 +206,46 @@ def test_ome_tiff_page_of_channel_and_z(tmp_path, order):
     assert tiff.select_page(tiff.TiffFile(q)) == 2
 
 
+def test_ome_tiffdata_blocks_map_planes_to_pages(tmp_path):
+    """TiffData elements that reorder and offset the planes (OME-TIFF specification); hand-built, tifffile absent."""
+    C, Z = 2, 3
+    pages = [_img(300 + i, 40, 60) for i in range(C * Z + 1)]       # page 0 is a stray leading page
+    chans = "".join(f'<Channel ID="Channel:0:{i}" Name="ch{i}"/>' for i in range(C))
+    head = ('<?xml version="1.0" encoding="UTF-8"?><OME xmlns="http://www.openmicroscopy.org/Schemas/OME/2016-06">'
+            f'<Image ID="Image:0"><Pixels ID="Pixels:0" DimensionOrder="XYZCT" Type="uint16" SizeX="60" SizeY="40" '
+            f'SizeC="{C}" SizeZ="{Z}" SizeT="1">{chans}')
+    tail = '</Pixels></Image></OME>'
+    # channel 1 first (pages 1..3), then channel 0 (pages 4..6), one block of three planes each
+    blocks = '<TiffData IFD="1" FirstC="1" FirstZ="0" PlaneCount="3"/><TiffData IFD="4" FirstC="0" FirstZ="0" PlaneCount="3"/>'
+    p = str(tmp_path / "E_1.ome.tiff")
+    _save(p, pages, description=head + blocks + tail)
+    t = tiff.TiffFile(p)
+    assert [t.ome_page(channel=1, z=z) for z in range(Z)] == [1, 2, 3]
+    assert [t.ome_page(channel=0, z=z) for z in range(Z)] == [4, 5, 6]
+    assert np.array_equal(tiff.read_tile(p, channel=0), pages[5])                  # the middle z of channel 0
+    # one TiffData per plane with IFD only counts one plane; a plane without a block raises
+    single = "".join(f'<TiffData IFD="{6 - k}" FirstC="{k // Z}" FirstZ="{k % Z}"/>' for k in range(C * Z - 1))
+    q = str(tmp_path / "E_2.ome.tiff")
+    _save(q, pages, description=head + single + tail)
+    tq = tiff.TiffFile(q)
+    assert tq.ome_page(channel=0, z=0) == 6 and tq.ome_page(channel=1, z=1) == 2
+    with pytest.raises(ValueError, match="no TiffData block"):
+        tq.ome_page(channel=1, z=2)
+    # a plane that lives in another file of a multi-file set
+    multi = ('<TiffData IFD="0" FirstC="0" PlaneCount="3"><UUID FileName="E_3.ome.tiff">urn:uuid:1</UUID></TiffData>'
+             '<TiffData IFD="0" FirstC="1" PlaneCount="3"><UUID FileName="E_3_c1.ome.tiff">urn:uuid:2</UUID></TiffData>')
+    r = str(tmp_path / "E_3.ome.tiff")
+    _save(r, pages, description=head + multi + tail)
+    tr_ = tiff.TiffFile(r)
+    assert tr_.ome_page(channel=0, z=2) == 2
+    with pytest.raises(ValueError, match="E_3_c1.ome.tiff"):
+        tr_.ome_page(channel=1, z=0)
+    # sizes that are not numbers: no usable OME description, the reference's middle-page fallback (:2236-2247)
+    bad = str(tmp_path / "E_4.ome.tiff")
+    _save(bad, pages[:5], description=head.replace(f'SizeZ="{Z}"', 'SizeZ="many"') + tail)
+    assert tiff.TiffFile(bad).ome_dims() is None and tiff.select_page(tiff.TiffFile(bad)) == 2
+
+
 def test_filename_patterns():
     assert tiff.parse_filename_fov_info("R0_12.ome.tiff") == {"region": "R0", "fov": 12}
     assert tiff.parse_filename_fov_info("R0_12_3_Fluorescence_488_nm_Ex.tiff") == {"region": "R0", "fov": 12, "z_level": 3}

@@ -13,12 +13,13 @@ from image_stitcher_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _fuse(entry, ctx, tiles, yx, plane, ffs, tff, n_planes, mh, mw, mode, rows=None):
+def _fuse(entry, ctx, tiles, yx, plane, ffs, tff, n_planes, mh, mw, mode, rows=None, out=None):
     import torch
     from image_stitcher_amd import _lib
     from image_stitcher_amd._lib import check, ptr
     t, h, w = (int(v) for v in tiles.shape)
-    out = torch.full((n_planes, mh, mw), 0x5a5a, dtype=torch.int16, device=tiles.device)
+    if out is None:
+        out = torch.full((n_planes, mh, mw), 0x5a5a, dtype=torch.int16, device=tiles.device)
     ff_type = _lib.FF_NONE if ffs is None else (_lib.FF_F32 if ffs.dtype == torch.float32 else _lib.FF_F64)
     r0, r1 = (0, mh) if rows is None else rows
     check(entry(ctx.handle, ptr(tiles), t, h, w, h * w, ptr(yx), ptr(plane), ptr(ffs), ff_type, ptr(tff), ptr(out),
@@ -52,9 +53,19 @@ def test_static_workspace_fusion_equals_the_allocating_one():
     # first call: the larger input; second: fewer, smaller tiles, a smaller mosaic, the other mode
     big = case(11, 4, 5, 300, 420, 2, _lib.FUSE_FEATHER, True)
     small = case(12, 2, 3, 130, 97, 1, _lib.FUSE_OVERWRITE, False, drop=1)
-    got_big = _fuse(lib.mistitch_fuse_static, ctx, *big)
-    got_small = _fuse(lib.mistitch_fuse_static, ctx, *small)
+    # The property the entry point exists for: no device memory is taken or given back during the calls.  The
+    # library's own hipMalloc would bypass torch's caching allocator and show in the driver's free-memory figure;
+    # the outputs are allocated beforehand so that torch does not move it either.
+    out_big = torch.full((big[5], big[6], big[7]), 0x5a5a, dtype=torch.int16, device=dev)
+    out_small = torch.full((small[5], small[6], small[7]), 0x5a5a, dtype=torch.int16, device=dev)
+    warm = torch.full((small[5], small[6], small[7]), 0x5a5a, dtype=torch.int16, device=dev)
+    _fuse(lib.mistitch_fuse_static, ctx, *small, out=warm)   # code objects loaded, kernels resident
     torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info(dev)[0]
+    got_big = _fuse(lib.mistitch_fuse_static, ctx, *big, out=out_big)
+    got_small = _fuse(lib.mistitch_fuse_static, ctx, *small, out=out_small)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == free_before, "device memory was allocated or freed during mistitch_fuse_static"
     want_big = _fuse(lib.mistitch_fuse, ctx, *big)
     want_small = _fuse(lib.mistitch_fuse, ctx, *small)
     assert torch.equal(got_big, want_big)
@@ -78,7 +89,7 @@ def test_static_workspace_fusion_equals_the_allocating_one():
     assert rc == _lib.ERR_UNSUPPORTED
     assert b"static" in lib.mistitch_last_error()
     torch.cuda.synchronize()
-    assert bool((huge == 0x5a5a).all())
+    assert all(bool((huge[:, r:r + 4000] == 0x5a5a).all()) for r in range(0, huge_h, 4000))   # in slices: no 8 GB temporary
     # the allocating entry point takes the same call
     rc = lib.mistitch_fuse(ctx.handle, _lib.ptr(tiles), int(tiles.shape[0]), 130, 97, 130 * 97, _lib.ptr(d_yx),
                            _lib.ptr(plane), None, _lib.FF_NONE, None, _lib.ptr(huge), 1, huge_h, huge_w, 0, huge_h, mode)
