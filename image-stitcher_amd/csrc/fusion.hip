@@ -385,15 +385,19 @@ template <int FF, bool SAFE>
 __device__ __forceinline__ Px8 corrected8_packed(const Px8& v, const F8& f32, const D8& f64, unsigned vmax) {
   if constexpr (FF == MISTITCH_FF_F32 && SAFE) {
     typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-    const us2 top = {(unsigned short)vmax, (unsigned short)vmax};  // the pixel type's largest value (one v_pk_min_u16 per dword)
+    const us2 top = {(unsigned short)vmax, (unsigned short)vmax};
     Px8 o;
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
       const unsigned d = v.d[p];
       const f2 n = {(float)(d & 0xffffu), (float)(d >> 16)};
       const f2 q = div2_u16(n, f2{f32.v[2 * p], f32.v[2 * p + 1]});
-      o.d[p] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(
-                   __builtin_bit_cast(us2, pack2((unsigned int)q.x, (unsigned int)q.y)), top));
+      o.d[p] = pack2((unsigned int)q.x, (unsigned int)q.y);  // saturates at 65535
+    }
+    if (vmax != 65535u) {  // (the same for every lane) 8-bit tiles: the pixel type's largest value is smaller
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        o.d[p] = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(us2, o.d[p]), top));
     }
     return o;
   } else {
@@ -523,7 +527,7 @@ struct ChunkGeom {
 //   sources less one (0: resolve pixel by pixel), 15-30 their candidate indices: two of 5
 //   bits, or three or four of 4 bits, the last placed in the lowest bits.
 // Blend entries fill the queue from the bottom, pixel-by-pixel entries from the top.
-template <int MODE, int FF, int GX, bool SAFE>
+template <int MODE, int FF, int GX, bool SAFE, bool CH>
 __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsigned* queue_len,
                                            const uint16_t* __restrict__ tiles, int n_tiles, int H, int W,
                                            int64_t tile_pitch, const int32_t* __restrict__ tile_yx,
@@ -565,7 +569,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
   const bool overflow = total > kMaxCand;
   const bool generic_only = overflow || W < 8 || Wm < 8;
   const int ncand = overflow ? n_tiles : total;
-  const bool chunked = cg.on();
+  constexpr bool chunked = CH;  // (cg.on())
   uint16_t* mplane = mosaic + (chunked ? (int64_t)plane * cg.plane_elems() : (int64_t)plane * Hm * Wm);
   const int Wp = chunked ? cg.Wp() : Wm;  // columns that are written
   const int w_idx = bx * (64 * GX) + lane;  // first aligned group of this lane within a row
@@ -604,7 +608,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
     uint16_t* rowp = mplane + (chunked ? cg.row_base(y) : (int64_t)y * Wm);
     const int a = chunked ? 0 : (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
     const int64_t yW = (int64_t)y * W;
-    if (y >= Hm) {  // (chunk order) a row of the last chunks below the mosaic: zeros, whatever tiles stick out that far
+    if (chunked && y >= Hm) {  // (chunk order) a row of the last chunks below the mosaic: zeros, whatever tiles stick out that far
 #pragma unroll
       for (int r = 0; r < GX; ++r) {
         const int x = 8 * w_idx + 512 * r;
@@ -772,7 +776,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
 
 // `ff_safe` points at the verdict of k_ff_check (1: every flatfield value used by this
 // call admits the scaling-free division).
-template <int MODE, int FF, int GX>
+template <int MODE, int FF, int GX, bool CH>
 __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restrict__ tiles, int n_tiles, int H,
                                                        int W, int64_t tile_pitch,
                                                        const int32_t* __restrict__ tile_yx,
@@ -789,13 +793,13 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
   __shared__ unsigned queue_len[3];  // blend entries, pixel-by-pixel entries, candidates with a flatfield plane
   if constexpr (FF == MISTITCH_FF_F32) {
     if (*ff_safe) {
-      fuse_block<MODE, FF, GX, true>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
+      fuse_block<MODE, FF, GX, true, CH>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
                                      flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes, idle_off,
                                      idle_foff, cg, vmax);
       return;
     }
   }
-  fuse_block<MODE, FF, GX, false>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
+  fuse_block<MODE, FF, GX, false, CH>(list, queue, queue_len, tiles, n_tiles, H, W, tile_pitch, tile_yx, tile_plane,
                                   flatfields, tile_ff, bins, mosaic, Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff, cg, vmax);
 }
 
@@ -972,9 +976,14 @@ static void launch_fuse(mistitch_ctx* ctx, dim3 grid, const uint16_t* tiles, int
                         int row1, int64_t idle_off, int64_t idle_foff, const ChunkGeom& cg) {
   const int gx = (int)grid.x, gy = (int)grid.y, n_planes = (int)grid.z;
   const unsigned n_wg = 8u * gx * (unsigned)((gy * n_planes + 7) / 8);
-  MS_LAUNCH(ctx, MODE == MISTITCH_FUSE_OVERWRITE ? "k_fuse_overwrite" : "k_fuse_feather", (k_fuse<MODE, FF, GX>),
-            dim3(n_wg), dim3(kFuseThreads), 0, tiles, n_tiles, H, W, pitch, yx, plane, ffs, tff, bins, ff_safe, mosaic,
-            Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff, cg, (unsigned)ctx->pixel_max);
+  if (cg.chunk_h != 0)
+    MS_LAUNCH(ctx, MODE == MISTITCH_FUSE_OVERWRITE ? "k_fuse_overwrite" : "k_fuse_feather", (k_fuse<MODE, FF, GX, true>),
+              dim3(n_wg), dim3(kFuseThreads), 0, tiles, n_tiles, H, W, pitch, yx, plane, ffs, tff, bins, ff_safe, mosaic,
+              Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff, cg, (unsigned)ctx->pixel_max);
+  else
+    MS_LAUNCH(ctx, MODE == MISTITCH_FUSE_OVERWRITE ? "k_fuse_overwrite" : "k_fuse_feather", (k_fuse<MODE, FF, GX, false>),
+              dim3(n_wg), dim3(kFuseThreads), 0, tiles, n_tiles, H, W, pitch, yx, plane, ffs, tff, bins, ff_safe, mosaic,
+              Hm, Wm, row0, row1, gx, gy, n_planes, idle_off, idle_foff, cg, (unsigned)ctx->pixel_max);
 }
 
 }  // namespace mistitch

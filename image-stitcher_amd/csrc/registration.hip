@@ -2714,6 +2714,11 @@ __device__ __forceinline__ void sweep_rows(const uint16_t* __restrict__ a, const
     const uint16_t* br = b + (int64_t)r * pitch;
     const U16x8 va0 = *reinterpret_cast<const U16x8*>(ar), va1 = *reinterpret_cast<const U16x8*>(ar + pitch);
     U16x8 xa0{}, xa1{}, xb0{}, xb1{};
+#if defined(MS_SWEEP_ABLATE) && MS_SWEEP_ABLATE == 1  /* measurement build: the second strip is not loaded */
+    xa0 = xb0 = va1;
+    xa1 = xb1 = va0;
+    (void)br;
+#else
     if constexpr (LA) {
       xa0 = *reinterpret_cast<const U16x8*>(br + off_a);
       xa1 = *reinterpret_cast<const U16x8*>(br + pitch + off_a);
@@ -2722,10 +2727,17 @@ __device__ __forceinline__ void sweep_rows(const uint16_t* __restrict__ a, const
       xb0 = *reinterpret_cast<const U16x8*>(br + off_b);
       xb1 = *reinterpret_cast<const U16x8*>(br + pitch + off_b);
     }
+#endif
+#if defined(MS_SWEEP_ABLATE) && MS_SWEEP_ABLATE == 2  /* measurement build: loads only */
+    acc.a_l ^= va0.d[0] ^ va0.d[1] ^ va0.d[2] ^ va0.d[3] ^ va1.d[0] ^ va1.d[1] ^ va1.d[2] ^ va1.d[3] ^ xa0.d[0] ^ xa0.d[1] ^
+               xa0.d[2] ^ xa0.d[3] ^ xb0.d[0] ^ xb0.d[1] ^ xb0.d[2] ^ xb0.d[3] ^ xa1.d[0] ^ xa1.d[1] ^ xa1.d[2] ^ xa1.d[3] ^
+               xb1.d[0] ^ xb1.d[1] ^ xb1.d[2] ^ xb1.d[3];
+#else
     acc.add4<LA, LB>(va0.d[0], va0.d[1], xa0.d[0], xa0.d[1], xb0.d[0], xb0.d[1]);
     acc.add4<LA, LB>(va0.d[2], va0.d[3], xa0.d[2], xa0.d[3], xb0.d[2], xb0.d[3]);
     acc.add4<LA, LB>(va1.d[0], va1.d[1], xa1.d[0], xa1.d[1], xb1.d[0], xb1.d[1]);
     acc.add4<LA, LB>(va1.d[2], va1.d[3], xa1.d[2], xa1.d[3], xb1.d[2], xb1.d[3]);
+#endif
   }
   if (r < r1) {
     const uint16_t* ar = a + (int64_t)r * pitch;
@@ -2750,12 +2762,14 @@ __global__ __launch_bounds__(kThreads, MS_SWEEP_OCC) void k_ncc_sweep(const Pair
   const int per_pair = n_peaks * 2 * n_row_chunks * n_col_chunks;
   const int pz = xcd + kXcds * (seq / per_pair);
   if (pz >= n_in_pass) return;
+  // a pair's workgroups in row order: the sweeps of all peaks and both row lags over the same rows of the first strip
+  // are neighbours in the grid and read those rows from L2 at about the same time
   int within = seq % per_pair;
   const int cc = within % n_col_chunks;
   within /= n_col_chunks;
-  const int ch = within % n_row_chunks;
-  within /= n_row_chunks;
-  const int sig = within & 1, pk = within >> 1;
+  const int sig = within & 1;
+  within >>= 1;
+  const int pk = within % n_peaks, ch = within / n_peaks;
   const int p = pair0 + pz;
   const int8_t st = status[p];
   const Peak peak = peaks[(int64_t)p * kMaxK + pk];
@@ -2766,11 +2780,26 @@ __global__ __launch_bounds__(kThreads, MS_SWEEP_OCC) void k_ncc_sweep(const Pair
   const int S = d.S, L = d.L;
   // rows: lag +n pairs row r with row r - n (r >= n: shift +n) or r - n + S (r < n: shift -(S - n)); lag -n pairs it
   // with r + n (r < S - n: shift -n) or r + n - S (shift +(S - n))
+  // Row chunks: the fixed blocks [j R, (j + 1) R) of the strip, the one that holds the wrap row cut in two there, in row
+  // order (chunk ch of every sweep covers block ch or ch - 1).
   const int wrap_row = sig ? S - n : n;
-  const int n_below = (wrap_row + kSweepRows - 1) / kSweepRows;  // chunks of the rows before the wrap
-  const bool below = ch < n_below;
-  const int r0 = below ? ch * kSweepRows : wrap_row + (ch - n_below) * kSweepRows;
-  const int r1 = min(r0 + kSweepRows, below ? wrap_row : S);
+  const int jw = wrap_row / kSweepRows;
+  const bool cut_block = wrap_row % kSweepRows != 0;
+  int r0, r1;
+  bool below;
+  if (!cut_block || ch < jw) {
+    r0 = ch * kSweepRows;
+    r1 = min(r0 + kSweepRows, S);
+    below = r0 < wrap_row;
+  } else if (ch == jw) {
+    r0 = jw * kSweepRows;
+    r1 = wrap_row;
+    below = true;
+  } else {
+    r0 = max((ch - 1) * kSweepRows, wrap_row);
+    r1 = min(ch * kSweepRows, S);
+    below = false;
+  }
   if (r0 >= r1) return;
   const int row_mag = (sig != 0) != below ? 1 : 0;  // 0: magnitude n, 1: S - n
   const int row_pos = below ? 0 : 1;                // sign of the row shift

@@ -44,7 +44,7 @@ def short_name(full):
     aliases = {"k_transpose_strips64": "k_transpose_strips", "k_stage_strips64": "k_stage_strips",
                "k_stage_strips_any": "k_stage_strips", "k_edge_stats_staged": "k_edge_stats",
                "k_fft_long_fwd_reg": "k_fft_long_fwd", "k_fft_short_cps_reg": "k_fft_short_cps",
-               "k_fft_long_inv_reg": "k_fft_long_inv"}
+               "k_fft_long_inv_reg": "k_fft_long_inv", "k_ncc_sweep": "k_ncc_accumulate"}
     if name in aliases:
         return aliases[name]
     return name
