@@ -1320,7 +1320,35 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
 // N = 512 .. 4096 points on the register-resident engine: the stored half of two spectrum rows is spread over the
 // line in LDS as before, the adjoint passes run in registers, and the values are ranked where the last pass
 // leaves them.  grid (ceil(nblk / seq), pairs_in_pass), N / 8 lanes, blocks of two lines (nblk per strip).
-template <int N, bool ABS>
+// WIDE: more than two peaks (the ten-peak candidate set), one block of lines per workgroup.  Every wave finds the
+// ceil(k / waves) largest of its lanes' maxima; the smallest of those over the waves is a bound T that at least k
+// values of the block reach, so the k largest are all among the values >= T: those (a dozen or two) are appended to a
+// list in LDS and one wave ranks them.  A block with more than kInvListCap values >= T (massive ties) is ranked by k
+// rounds of a block-wide argmax over the registers instead.
+#ifndef MS_INV_LIST_CAP
+#define MS_INV_LIST_CAP 128
+#endif
+constexpr int kInvListCap = MS_INV_LIST_CAP;
+static_assert(kInvListCap <= 128 && kInvListCap >= 1, "one wave ranks the list, two entries per lane");
+
+// Largest value of a double over the wave, the same in every lane.
+__device__ __forceinline__ double wave_max_f64(double v) {
+  auto step = [&](unsigned long long o) { v = fmax(v, __longlong_as_double((long long)o)); };
+  step(dpp_u64<kDppXor1>((unsigned long long)__double_as_longlong(v)));
+  step(dpp_u64<kDppXor2>((unsigned long long)__double_as_longlong(v)));
+  step(dpp_u64<kDppHalfMirror>((unsigned long long)__double_as_longlong(v)));
+  step(dpp_u64<kDppMirror>((unsigned long long)__double_as_longlong(v)));
+  double m = v;
+#pragma unroll
+  for (int row = 0; row < 4; ++row) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((unsigned)bits, 16 * row), hi = __builtin_amdgcn_readlane((unsigned)(bits >> 32), 16 * row);
+    m = fmax(m, __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)));
+  }
+  return m;
+}
+
+template <int N, bool ABS, bool WIDE = false>
 __global__ __launch_bounds__(N / 8, 4) void k_fft_long_inv_reg(const PairDesc* desc, const int8_t* status, int pair0, int S,
                                                             int want_transposed, const double2* __restrict__ roots,
                                                             const uint16_t* __restrict__ stored_pos,
@@ -1333,6 +1361,9 @@ __global__ __launch_bounds__(N / 8, 4) void k_fft_long_inv_reg(const PairDesc* d
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double2* buf = reinterpret_cast<double2*>(smem_raw);
   __shared__ Peak red[2 * NW];
+  __shared__ Peak wide_list[WIDE ? kInvListCap : 1];
+  __shared__ double wide_thr[NW];
+  __shared__ int wide_n;
   const int p = pair0 + blockIdx.y;
   const int8_t pair_status = status[p];
   const PairDesc d = desc[p];
@@ -1410,13 +1441,91 @@ __global__ __launch_bounds__(N / 8, 4) void k_fft_long_inv_reg(const PairDesc* d
     MS_PIN(tw.p2.x); MS_PIN(tw.p2.y);
     F::inverse(v, buf, tw, tid);
     const bool have0 = s0 < S, have1 = s0 + 1 < S;  // an odd S leaves the last transform half empty
+    if constexpr (WIDE) {  // (seq == 1: this is the workgroup's only block)
+      const int lane = tid & 63, wave = tid >> 6;
+      auto val_of = [&](int e) { return (e & 1 ? v[e >> 1].y : v[e >> 1].x) * cmp_scale; };
+      auto key_of = [&](int e) {
+        const int l = tid + NT * (e >> 1);
+        const int key0 = d.transposed ? l * S + s0 : s0 * N + l;
+        return e & 1 ? (d.transposed ? key0 + 1 : key0 + N) : key0;
+      };
+      double lane_max = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) lane_max = ((e & 1) ? have1 : have0) ? fmax(lane_max, val_of(e)) : lane_max;
+      const int per_wave = (k + NW - 1) / NW;
+      double cur = lane_max, thr = -INFINITY;
+      for (int r = 0; r < per_wave; ++r) {  // the wave's per_wave-th largest lane maximum
+        thr = wave_max_f64(cur);
+        const unsigned long long at = __ballot(cur == thr);
+        if (at != 0ull && lane == __builtin_ctzll(at)) cur = -INFINITY;
+      }
+      if (lane == 0) wide_thr[wave] = thr;
+      if (tid == 0) wide_n = 0;
+      __syncthreads();
+      double bound = wide_thr[0];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) bound = fmin(bound, wide_thr[w]);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const double x = val_of(e);
+        if (((e & 1) ? have1 : have0) && x >= bound) {
+          const int at = atomicAdd(&wide_n, 1);
+          if (at < kInvListCap) wide_list[at] = Peak{x, key_of(e), at};
+        }
+      }
+      __syncthreads();
+      const int n_list = wide_n;
+      const Peak none{-INFINITY, -1, -1};
+      Peak* dst = partial + (int64_t)blockIdx.y * partial_stride + blk0 * k;
+      if (n_list <= kInvListCap) {  // (uniform) one wave ranks the list, two entries per lane
+        if (wave == 0) {
+          Peak e0 = lane < n_list ? wide_list[lane] : none;
+          Peak e1 = lane + 64 < n_list ? wide_list[lane + 64] : none;
+          for (int round = 0; round < k; ++round) {
+            const Peak mine = peak_better(e1.val, e1.key, e0.val, e0.key) ? e1 : e0;
+            const Peak w = wave_best_peak(mine, peak_better);
+            if (lane == 0) dst[round] = w.key >= 0 ? Peak{w.val * out_scale, w.key, w.key} : none;
+            if (w.key >= 0 && e0.loc == w.loc) e0 = none;
+            if (w.key >= 0 && e1.loc == w.loc) e1 = none;
+          }
+        }
+      } else {  // (uniform) too many values reach the bound: k rounds of a block-wide argmax over the registers
+        unsigned taken = 0;
+        for (int round = 0; round < k; ++round) {
+          Peak mine = none;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const double x = val_of(e);
+            const int key = key_of(e);
+            const bool ok = ((e & 1) ? have1 : have0) & !((taken >> e) & 1u) & peak_better(x, key, mine.val, mine.key);
+            mine.val = ok ? x : mine.val;
+            mine.key = ok ? key : mine.key;
+            mine.loc = ok ? tid * 16 + e : mine.loc;
+          }
+          const Peak w = wave_best_peak(mine, peak_better);
+          __syncthreads();
+          if (lane == 0) red[wave] = w;
+          __syncthreads();
+          Peak best = red[0];
+#pragma unroll
+          for (int q = 1; q < NW; ++q) {
+            const Peak o = red[q];
+            if (peak_better(o.val, o.key, best.val, best.key)) best = o;
+          }
+          if (tid == 0) dst[round] = best.key >= 0 ? Peak{best.val * out_scale, best.key, best.key} : none;
+          if (best.key >= 0 && (best.loc >> 4) == tid) taken |= 1u << (best.loc & 15);
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int l = tid + NT * j;
       const int key0 = d.transposed ? l * S + s0 : s0 * N + l;
       const int key1 = d.transposed ? key0 + 1 : key0 + N;
-      offer(v[j].x * cmp_scale, key0, have0);
-      offer(v[j].y * cmp_scale, key1, have1);
+      if constexpr (!WIDE) {
+        offer(v[j].x * cmp_scale, key0, have0);
+        offer(v[j].y * cmp_scale, key1, have1);
+      }
       if (want_abs) {
         const double a0v = fabs(v[j].x * scale), a1v = fabs(v[j].y * scale);
         const bool t0 = have0 & first_better(a0v, key0, ba.val, ba.key);
@@ -1442,6 +1551,7 @@ __global__ __launch_bounds__(N / 8, 4) void k_fft_long_inv_reg(const PairDesc* d
     if (tid > 0 && tid < seq && blk0 + tid < nblk) partial_abs[(int64_t)blockIdx.y * abs_stride + blk0 + tid] = none;
     __syncthreads();
   }
+  if constexpr (WIDE) return;  // the list entries were written where the values were ranked
   const Peak w1 = wave_best_peak(b1, peak_better);
   if (w1.loc >= 0 && w1.loc == b1.loc) b1 = b2;
   const Peak w2 = k > 1 ? wave_best_peak(b1, peak_better) : none;
@@ -4088,18 +4198,29 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
   // in turn and reduces once - as long as the launch still fills the chip a few times over.
   const int nblk_inv = (cfg.S + 2 * cfg.NF_inv - 1) / (2 * cfg.NF_inv);
   int seq = 1;
-  if (k > 0 && k <= 2 && pcm_out == nullptr)
+  if (k > 0 && k <= 2 && pcm_out == nullptr)   // (more peaks: one block per workgroup)
     while (seq < kLongInvSeq && (int64_t)((nblk_inv + 2 * seq - 1) / (2 * seq)) * n >= 2048) seq *= 2;
   bool inv_done = false;
   if constexpr (std::is_same<T, double>::value) {
     // two peaks at most and no correlation plane: the register-resident engine, for the line lengths it is built for
-    if (k > 0 && k <= 2 && pcm_out == nullptr && cfg.NF_inv == 1 && kLongMaxRadix<double> == 8 && !getenv("MISTITCH_FFT_LDS_ENGINE")) {
+    if (k > 0 && k <= kMaxK && pcm_out == nullptr && cfg.NF_inv == 1 && kLongMaxRadix<double> == 8 && !getenv("MISTITCH_FFT_LDS_ENGINE")) {
+      const bool wide_k = k > 2;
       const double2* roots = reinterpret_cast<const double2*>(cfg.planL.tw);
       Peak* pabs = ws.n_up ? ws.partial_abs : (Peak*)nullptr;
 #define MS_INV_REG(NN)                                                                                                \
   do {                                                                                                                \
     const size_t lds = (size_t)RegFft<NN>::kSlots * sizeof(double2);                                                  \
-    if (pabs != nullptr) {                                                                                            \
+    if (wide_k && pabs != nullptr) {                                                                                  \
+      if ((rc = allow_lds(ctx, k_fft_long_inv_reg<NN, true, true>, lds))) return rc;                                  \
+      MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv_reg<NN, true, true>), dim3(nblk_inv, n), dim3(NN / 8), lds,     \
+                ws.desc, status, pair0, cfg.S, want_transposed, roots, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored, \
+                spec, k, ws.partial, ws.partial_stride, pabs, ws.abs_stride, nblk_inv, 1);                            \
+    } else if (wide_k) {                                                                                              \
+      if ((rc = allow_lds(ctx, k_fft_long_inv_reg<NN, false, true>, lds))) return rc;                                 \
+      MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv_reg<NN, false, true>), dim3(nblk_inv, n), dim3(NN / 8), lds,    \
+                ws.desc, status, pair0, cfg.S, want_transposed, roots, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored, \
+                spec, k, ws.partial, ws.partial_stride, pabs, ws.abs_stride, nblk_inv, 1);                            \
+    } else if (pabs != nullptr) {                                                                                     \
       if ((rc = allow_lds(ctx, k_fft_long_inv_reg<NN, true>, lds))) return rc;                                        \
       MS_LAUNCH(ctx, "k_fft_long_inv", (k_fft_long_inv_reg<NN, true>), dim3((nblk_inv + seq - 1) / seq, n), dim3(NN / 8), lds, \
                 ws.desc, status, pair0, cfg.S, want_transposed, roots, cfg.stored_pos, cfg.mirror_fill, cfg.n_stored, \

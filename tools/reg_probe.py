@@ -2,7 +2,7 @@
 """Diagnostic: per-kernel durations of one registration step on the 20x20 grid of 2048^2 tiles (one channel, no
 flatfield), for library variants (MISTITCH_LIB=tools/variants/<name>.so).  Prints how many planted shifts came back,
 so a variant that breaks results on purpose (a store left out, ...) is still timed.
-usage: reg_probe.py [edge_width] [f64|f32] [steps]"""
+usage: reg_probe.py [edge_width] [f64|f32] [steps] [extra flags, e.g. 22 = consensus + ten peaks + subpixel]"""
 import os
 import sys
 import time
@@ -29,7 +29,7 @@ d_idx = torch.as_tensor(pair_idx, dtype=torch.int32, device=device)
 d_dir = torch.as_tensor(pair_dir, dtype=torch.uint8, device=device)
 out = torch.empty((n, 3), dtype=torch.float64, device=device)
 st = torch.empty((n,), dtype=torch.int8, device=device)
-flag = _lib.FFT_F64 if fft == "f64" else _lib.FFT_F32
+flag = (_lib.FFT_F64 if fft == "f64" else _lib.FFT_F32) | (int(sys.argv[4]) if len(sys.argv) > 4 else 0)
 
 
 def run():
@@ -46,7 +46,7 @@ for _ in range(steps):
 torch.cuda.synchronize()
 ms = 1e3 * (time.perf_counter() - t0) / steps
 expected = true_yx[pair_idx[:, 1]] - true_yx[pair_idx[:, 0]]
-good = int(((st.cpu().numpy() == 0) & (out.cpu().numpy()[:, 1:].astype(np.int64) == expected).all(axis=1)).sum())
+good = int(((st.cpu().numpy() == 0) & (np.rint(out.cpu().numpy()[:, 1:]).astype(np.int64) == expected).all(axis=1)).sum())
 ctx.profile(True)
 for _ in range(2):
     run()
