@@ -451,6 +451,84 @@ def fuzz_pipeline(rng, reg, fu, synth):
                             mode=mode), (one, banded, yx, plane)
 
 
+def fuzz_fusion_chunked(rng, fu, ofu, synth):
+    """The mosaic born in chunk order against the oracle's mosaic cut into zero-padded chunks: any chunk shape whose
+    width is a multiple of 8, both modes, flatfields, tiles cut by the mosaic's edges, one or several row bands."""
+    import torch
+    th, tw = int(rng.integers(5, 90)), int(rng.integers(5, 300))
+    n = int(rng.integers(0, 24))
+    planes = int(rng.integers(1, 3))
+    mh, mw = int(rng.integers(th, 3 * th + 40)), int(rng.integers(max(tw, 9), 4 * tw + 2600))
+    tiles = rng.integers(0, 65536, size=(n, th, tw)).astype(np.uint16)
+    yx = np.stack([rng.integers(-th // 2, mh, size=n), rng.integers(-tw // 2, mw, size=n)], axis=1).astype(np.int32) \
+        if n else np.zeros((0, 2), dtype=np.int32)
+    plane = rng.integers(0, planes, size=n).astype(np.int32)
+    with_ff = rng.random() < 0.5 and n > 0
+    ffs = np.stack([synth.make_flatfield(th, tw, amplitude=float(rng.uniform(0, 0.6))) for _ in range(planes)]) if with_ff else None
+    mode = "overwrite" if rng.random() < 0.5 else "feather"
+    ch, cw = int(rng.integers(1, 2 * mh)), 8 * int(rng.integers(1, max(2, mw // 6)))
+    oracle = ofu.fuse_overwrite if mode == "overwrite" else ofu.fuse_feather
+    # the oracle places whole tiles: clip them to the mosaic first, as the reference's place_tile does (stitcher.py:290-294)
+    want = np.zeros((planes, mh, mw), dtype=np.uint16) if n == 0 else None
+    if n:
+        want = oracle(tiles, yx, plane, planes, mh, mw, flatfields=ffs, tile_ff=plane if with_ff else None) \
+            if (yx >= 0).all() else None
+    ncy, ncx = -(-mh // ch), -(-mw // cw)
+    kw = dict(flatfields=ffs, tile_ff=plane if with_ff else None, mode=mode)
+    plain = fu.fuse_tiles(tiles, yx, plane, planes, mh, mw, **kw).cpu().view(torch.int16).numpy().view(np.uint16)
+    if want is not None and not np.array_equal(plain, want):
+        return False, dict(kind="fusion_chunked", stage="plain mosaic", tile=(th, tw), n=n, mosaic=(mh, mw), mode=mode), (plain, want, yx, plane)
+    padded = np.zeros((planes, ncy * ch, ncx * cw), dtype=np.uint16)
+    padded[:, :mh, :mw] = plain
+    want_chunks = padded.reshape(planes, ncy, ch, ncx, cw).transpose(0, 1, 3, 2, 4)
+    if rng.random() < 0.5 or mh < 3:
+        got = fu.fuse_tiles(tiles, yx, plane, planes, mh, mw, chunks=(ch, cw), **kw)
+    else:
+        cut = sorted(int(v) for v in rng.integers(1, mh, size=2))
+        got = torch.full((planes, ncy, ncx, ch, cw), 0x1234, dtype=torch.int16, device="cuda").view(torch.uint16)
+        for r0, r1 in ((0, cut[0]), (cut[0], cut[1]), (cut[1], mh)):
+            fu.fuse_tiles(tiles, yx, plane, planes, mh, mw, chunks=(ch, cw), rows=(r0, r1), out=got, **kw)
+    got = got.cpu().view(torch.int16).numpy().view(np.uint16)
+    return bool(np.array_equal(got, want_chunks)), dict(kind="fusion_chunked", tile=(th, tw), n=n, planes=planes, mosaic=(mh, mw),
+                                                        chunk=(ch, cw), mode=mode, ff=with_ff), (got, want_chunks, yx, plane)
+
+
+def fuzz_u8(rng, fu, ofu, synth):
+    """8-bit tiles: flatfield correction clipped to 255 and fusion in both modes against the oracle (uint8 in, uint8 out)."""
+    th, tw = int(rng.integers(5, 90)), int(rng.integers(5, 140))
+    n = int(rng.integers(1, 20))
+    planes = int(rng.integers(1, 3))
+    mh, mw = int(rng.integers(th, 3 * th + 40)), int(rng.integers(tw, 3 * tw + 300))
+    tiles = rng.integers(0, 256, size=(n, th, tw)).astype(np.uint8)
+    yx = np.stack([rng.integers(0, max(1, mh - th // 2), size=n), rng.integers(0, max(1, mw - tw // 2), size=n)], axis=1).astype(np.int32)
+    plane = rng.integers(0, planes, size=n).astype(np.int32)
+    dt = np.float32 if rng.random() < 0.7 else np.float64
+    ffs = np.stack([synth.make_flatfield(th, tw, dtype=dt, amplitude=float(rng.uniform(0, 0.9))) for _ in range(planes)])
+    one = fu.apply_flatfield_to_image(tiles[0], ffs[0])
+    if one.dtype != np.uint8 or not np.array_equal(one, ofu.apply_flatfield(tiles[0], ffs[0])):
+        return False, dict(kind="u8", stage="flatfield", tile=(th, tw)), (one[None], ofu.apply_flatfield(tiles[0], ffs[0])[None], yx, plane)
+    mode = "overwrite" if rng.random() < 0.5 else "feather"
+    oracle = ofu.fuse_overwrite if mode == "overwrite" else ofu.fuse_feather
+    want = oracle(tiles, yx, plane, planes, mh, mw, flatfields=ffs, tile_ff=plane)
+    got = fu.fuse_tiles(tiles, yx, plane, planes, mh, mw, flatfields=ffs, tile_ff=plane, mode=mode).cpu().numpy()
+    return bool(got.dtype == np.uint8 and np.array_equal(got, want)), dict(kind="u8", tile=(th, tw), n=n, mosaic=(mh, mw), mode=mode), \
+        (got, want, yx, plane)
+
+
+def fuzz_bitshuffle(rng, fu, ofu, synth):
+    """The bitshuffle filter against its NumPy definition: any length, element size and block size."""
+    import torch
+    from image_stitcher_amd import omezarr
+    es = int(rng.choice([1, 2, 4, 8]))
+    n = int(rng.integers(1, 40000))
+    block = es * int(rng.choice([8, 64, 256, 2048, 4096, int(rng.integers(1, 5000))]))
+    raw = rng.integers(0, 256, size=n * es, dtype=np.uint8)
+    got = omezarr.bitshuffle(torch.from_numpy(raw).cuda(), es, block).cpu().numpy()
+    want = omezarr.bitshuffle_numpy(raw, es, block)
+    return bool(np.array_equal(got, want)), dict(kind="bitshuffle", elems=n, elem_size=es, block_bytes=block), \
+        (got[None, None], want[None, None], np.zeros((0, 2)), np.zeros(0))
+
+
 def fuzz_fusion_wide(rng, fu, ofu, synth):
     """Mosaics several blocks wide and tall (a block is 32 rows by 2048 pixels), few tall tiles."""
     th, tw = int(rng.integers(8, 120)), int(rng.integers(200, 1700))
@@ -502,7 +580,10 @@ def main():
                "mixed_radix": lambda: fuzz_mixed_radix(rng, reg, oreg, synth),
                "peaks10": lambda: fuzz_peaks10(rng, reg, oreg, synth),
                "window": lambda: fuzz_window(rng, reg, oreg, synth),
-               "consensus": lambda: fuzz_consensus(rng, reg, oreg, synth)}
+               "consensus": lambda: fuzz_consensus(rng, reg, oreg, synth),
+               "fusion_chunked": lambda: fuzz_fusion_chunked(rng, fu, ofu, synth),
+               "u8": lambda: fuzz_u8(rng, fu, ofu, synth),
+               "bitshuffle": lambda: fuzz_bitshuffle(rng, fu, ofu, synth)}
     kinds = [k for k in runners if not args.only or k in args.only.split(",")]
     counts = {k: 0 for k in kinds}
     last = t0
