@@ -391,7 +391,13 @@ __device__ __forceinline__ Px8 corrected8_packed(const Px8& v, const F8& f32, co
     for (int p = 0; p < 4; ++p) {
       const unsigned d = v.d[p];
       const f2 n = {(float)(d & 0xffffu), (float)(d >> 16)};
+#if defined(MS_FUSE_ABLATE) && MS_FUSE_ABLATE == 1   /* measurement build: a product in place of the quotient */
+      const f2 q = n * f2{f32.v[2 * p], f32.v[2 * p + 1]};
+#elif defined(MS_FUSE_ABLATE) && MS_FUSE_ABLATE == 2  /* measurement build: no arithmetic on the pixels at all */
+      const f2 q = {__uint_as_float(d) + f32.v[2 * p], f32.v[2 * p + 1]};
+#else
       const f2 q = div2_u16(n, f2{f32.v[2 * p], f32.v[2 * p + 1]});
+#endif
       o.d[p] = pack2((unsigned int)q.x, (unsigned int)q.y);  // saturates at 65535
     }
     if (vmax != 65535u) {  // (the same for every lane) 8-bit tiles: the pixel type's largest value is smaller

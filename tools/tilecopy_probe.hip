@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256) void k_tile_rows(const uint16_t* __restrict__ 
 
 // One group per lane: a workgroup of 256 lanes takes ONE tile row (4 KiB); LOOP = 1: and walks the 20 tiles
 // of the grid row with the flatfield values of its 8 pixels in registers; LOOP = 0: one tile, flatfield from memory.
-template <bool FF, int LOOP, int PF>
+// FFMODE (timing only, the values then belong to other pixels): 1 = the flatfield loads of a wave are contiguous
+// (16 bytes per lane at a 16-byte stride, two halves of the row) instead of 16 bytes at a 32-byte stride;
+// 2 = non-temporal flatfield loads; 3 = one 16-byte load only (half the flatfield bytes).
+template <bool FF, int LOOP, int PF, int FFMODE = 0>
 __global__ __launch_bounds__(256) void k_tile_row1(const uint16_t* __restrict__ tiles, const float* __restrict__ ffs,
                                                    const int* __restrict__ yx, uint16_t* __restrict__ mosaic, int Hm, int Wm) {
   const int lane = threadIdx.x & 63, j = threadIdx.x;
@@ -182,8 +185,20 @@ __global__ __launch_bounds__(256) void k_tile_row1(const uint16_t* __restrict__ 
   f4 ff[2];
   if constexpr (FF) {
     const float* f = ffs + ((size_t)p * T + ly) * T + 8 * j;
-    ff[0] = *reinterpret_cast<const f4*>(f);
-    ff[1] = *reinterpret_cast<const f4*>(f + 4);
+    if constexpr (FFMODE == 1) {
+      const float* g = ffs + ((size_t)p * T + ly) * T + 4 * j;
+      ff[0] = *reinterpret_cast<const f4*>(g);
+      ff[1] = *reinterpret_cast<const f4*>(g + T / 2);
+    } else if constexpr (FFMODE == 2) {
+      ff[0] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(f));
+      ff[1] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(f + 4));
+    } else if constexpr (FFMODE == 3) {
+      ff[0] = *reinterpret_cast<const f4*>(f);
+      ff[1] = ff[0];
+    } else {
+      ff[0] = *reinterpret_cast<const f4*>(f);
+      ff[1] = *reinterpret_cast<const f4*>(f + 4);
+    }
   }
   u4 nxt, nxt_prev;
   if constexpr (PF) {
@@ -413,6 +428,11 @@ int main() {
   run("ff, 1 row/wave, band fastest + prefetch", [&] { k_tile_rows<true, 1, 1, 1><<<CH * (T / 4) * GRID, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
   run("no ff, band fastest + prefetch", [&] { k_tile_rows<false, 1, 1, 1><<<CH * (T / 4) * GRID, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
   const unsigned n_rows_all = (unsigned)(n_tiles * T), n_rows_loop = (unsigned)(CH * GRID * T);
+  run("1 group/lane, one tile row per WG, no ff", [&] { k_tile_row1<false, 0, 0><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
+  run("1 group/lane, one tile row per WG, ff mem", [&] { k_tile_row1<true, 0, 0><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
+  run("  the same, contiguous ff loads (timing)", [&] { k_tile_row1<true, 0, 0, 1><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
+  run("  the same, non-temporal ff loads", [&] { k_tile_row1<true, 0, 0, 2><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
+  run("  the same, half the ff bytes (timing)", [&] { k_tile_row1<true, 0, 0, 3><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
   run("1 group/lane, one tile row per WG, no ff", [&] { k_tile_row1<false, 0, 0><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
   run("1 group/lane, one tile row per WG, ff mem", [&] { k_tile_row1<true, 0, 0><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
   run("1 group/lane, 20 tiles per WG, no ff", [&] { k_tile_row1<false, 1, 0><<<n_rows_loop, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
