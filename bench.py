@@ -500,6 +500,16 @@ def main():
             tf = n_pairs * fl / (kernels[name]["ms_per_step"] * 1e-3) / 1e12
             kernels[name]["fp64_tflops"] = tf
             kernels[name]["fp64_frac"] = tf / FP64_PEAK_TFLOPS
+    # the first subpixel stage: its matrix products against the float64 matrix-core peak (one column of every
+    # conjugate pair x edge frequencies x 32 node displacements, 8 flops per complex multiply-add) and the normalised
+    # spectrum it streams against HBM
+    if "k_ups_short" in kernels and kernels["k_ups_short"]["ms_per_step"] > 0:
+        sec = kernels["k_ups_short"]["ms_per_step"] * 1e-3
+        cols_half = tile // 2 + 1
+        tf = n_pairs * cols_half * edge * 32 * 8.0 / sec / 1e12
+        gbs = n_pairs * cols_half * (edge * 16 + 32 * 16) / sec / 1e9
+        kernels["k_ups_short"].update(mfma_fp64_tflops=tf, mfma_fp64_frac=tf / FP64_PEAK_TFLOPS, hbm_gbs=gbs,
+                                      hbm_frac=gbs / HBM_PEAK_GBS)
     # the dominant kernel of the configured step (the other fusion mode is a side figure)
     in_step = [n for n in rooflines if n != f"k_fuse_{other_mode}"]
     dominant = max(in_step, key=lambda n: kernels[n]["ms_per_step"]) if in_step else None

@@ -23,6 +23,8 @@ extern "C" int mistitch_create(int device, void* stream, mistitch_ctx** out) {
   mistitch_ctx* ctx = new mistitch_ctx();
   ctx->device = device;
   ctx->stream = reinterpret_cast<hipStream_t>(stream);
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->n_cus = cus;
   *out = ctx;
   return MISTITCH_OK;
 }

@@ -148,6 +148,7 @@ struct Profiler {
 // The opaque handle of the C ABI.
 struct mistitch_ctx {
   int device = 0;
+  int n_cus = 256;  // compute units of the device
   hipStream_t stream = nullptr;
   int pair_chunk = 128;  // pairs processed per pipeline pass (bounds the FFT workspace)
   int64_t staging_limit = 4ll << 30;  // strips of all pairs of a call are staged at once up to this many bytes
@@ -161,6 +162,7 @@ struct mistitch_ctx {
   std::vector<void*> shape_allocs;                // device tables owned by those configurations
   std::map<int, std::vector<char>> gen_plans;     // chirp-z plans by transform length
   std::map<long long, void*> gen_tables;          // subpixel column tables of chirp-z strip shapes (freed with shape_allocs)
+  std::map<int, void*> ups_grid_tables;           // subpixel node displacements and interpolation matrix by upsample factor (freed with shape_allocs)
   std::map<int, void*> hann_tables;               // symmetric Hann windows by length, float64 (freed with shape_allocs)
   mistitch::Profiler prof;
 };

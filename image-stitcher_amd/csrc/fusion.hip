@@ -702,7 +702,11 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
       const TileRef* c = list + ((csel >> (5 * r)) & 31u);
       const int64_t at = yW + x;
       const int64_t off = k == 1 ? c->src_base + at : idle_off;
+#if defined(MS_FUSE_ABLATE) && MS_FUSE_ABLATE == 3  /* measurement build: every flatfield load of a copy falls into one 64 KiB window */
+      const int64_t foff = (k == 1 ? c->ff_base + at : idle_foff) & 0x3fff;
+#else
       const int64_t foff = k == 1 ? c->ff_base + at : idle_foff;
+#endif
       v[r] = *reinterpret_cast<const Px8*>(tiles + off);
       if constexpr (FF == MISTITCH_FF_F32)
         f32[r] = *reinterpret_cast<const F8*>(reinterpret_cast<const char*>(flatfields) + foff * (int64_t)ffsize);

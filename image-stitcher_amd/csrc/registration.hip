@@ -51,7 +51,8 @@ constexpr int kNccChunks = 8;   // workgroups cooperating on one candidate (2, 4
 // A pair has n_cand + 1 candidate slots (n_cand = kNumCand or kNumCandWide, a kernel argument): the last slot
 // holds the subpixel estimate's rounded shift (flag 1 when unused).
 constexpr int kUpsMax = 160;    // largest upsampled region side (ceil(1.5 * upsample factor))
-constexpr int kUpsRows = 80;    // upsampled rows per block of the second stage (five 16-row tiles)
+constexpr int kUpsNodes = 32;   // Chebyshev nodes per axis at which the subpixel stage evaluates the correlation (two 16-row tiles)
+constexpr int kUpsRows = 16;    // rows of the upsampled grid per workgroup of the interpolation kernel (one matrix tile)
 
 struct PairDesc {
   const uint16_t* a;  // canonical strip of the first tile
@@ -2038,6 +2039,15 @@ __global__ __launch_bounds__(kThreads) void k_peaks_candidates(const PairDesc* d
 // where c_b = -2i sin(pi ds) conj(R[S/2, b]) accounts for the Nyquist row, whose signed
 // frequency is not negated by conjugation; self-conjugate columns contribute X_b e_b
 // (second stage, k_ups_long).
+//
+// Every term of CC is exp(i (ws ds + wl dl)) with |ws|, |wl| <= pi, and the grid spans only
+// h = (n_up - 1) / (2 u) ~ 0.75 pixels either side of its centre: along each axis CC is an entire function of
+// exponential type pi h ~ 2.4 on [-1, 1], which the polynomial through kUpsNodes = 32 Chebyshev nodes reproduces
+// to rounding error (truncation 2 (pi h / 2)^32 / 32! ~ 1e-33 of the largest possible |CC|, Lebesgue constant 3.2;
+// measured against the direct sums: 2e-15 of the peak).  The two stages therefore evaluate CC at the 32 x 32 node
+// displacements only (a fifth of the first stage's products, a twentieth of the second's) and k_ups_interp
+// carries the node values to the n_up x n_up grid with the barycentric interpolation matrix P (n_up x 32, built
+// on the host in extended precision): CC_grid = P CC_nodes P^T.
 // Coarse shift of the subpixel stage: the pair's largest |PCM| value (first in row-major
 // order on ties), wrapped to signed about the midpoint.  grid (pairs_in_pass).
 __global__ __launch_bounds__(kThreads) void k_ups_coarse(const PairDesc* desc, const int8_t* status, int pair0, int S,
@@ -2081,18 +2091,15 @@ struct KappaEntry {
 };
 
 // First stage on the matrix cores.  For one slab (8 columns) X[u][c] = sum_kk R[kk][c] E[u][kk],
-// E[u][kk] = exp(i theta_u (kk - S/2)), is a real product C = A B with
+// E[u][kk] = exp(i theta_u (kk - S/2)), u the kUpsNodes node displacements, is a real product C = A B with
 //   A[u][2 kk + p]       = p ? Im E : Re E                       (generated: one rotor per lane)
 //   B[2 kk + p][2 c + o] = (p == o) ? Re R : (p ? -Im R : Im R)  (one double per lane from LDS)
 //   C[u][2 c + o]        = o ? Im X : Re X
 // run as v_mfma_f64_16x16x4_f64 steps: lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15];
 // result register g of lane l is C[(l >> 4) + 4 g][l & 15].  A step covers two kk.
-// grid (ceil(n_slabs / NS), pairs_in_pass), four waves.  A workgroup holds NS slabs in LDS.  Float64 vector
-// work (the rotor updates) and the float64 matrix instructions compete for the same units, so a rotor has
-// to serve several products: wave w takes the displacement tiles 2w and 2w + 1 against all NS slabs and tile
-// 8 + (w & 1) against half of them (the lower half for w < 2), three rotor updates for 5 NS / 2 products.
+// grid (ceil(n_slabs / NS), pairs_in_pass), four waves.  A workgroup holds NS slabs in LDS.
 typedef double d4 __attribute__((ext_vector_type(4)));
-static_assert(kUpsMax <= 160, "ten 16-row tiles cover the upsampled region");
+static_assert(kUpsNodes == 32, "two 16-row tiles of node displacements");
 
 template <typename T, int NS>
 __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, const int8_t* status, int pair0, int S,
@@ -2101,7 +2108,7 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
                                                         const uint16_t* __restrict__ pos2stored,
                                                         const uint16_t* __restrict__ stored2kappa, int n_stored,
                                                         const cx<T>* __restrict__ rslabs,
-                                                        const UpsState* __restrict__ ups, int n_up, double uf,
+                                                        const UpsState* __restrict__ ups, const double* __restrict__ node,
                                                         double2* __restrict__ T1, double2* __restrict__ Nq) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* rows = reinterpret_cast<double*>(smem_raw);  // [NS][S][2 * kSlab], rows in ascending signed frequency
@@ -2133,7 +2140,11 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
     const cx<T>* slab = Rs + (slab_pos[min(slab0 + ns, n_slabs - 1)] / kSlab) * sp;
     double* dst = rows + ns * slab_elems;
     constexpr int U = 8;  // loads in flight per lane: one at a time would leave the workgroup waiting on memory
+#if defined(MS_UPS_ABLATE) && MS_UPS_ABLATE == 1  /* measurement build: no slab loads */
+    for (int e0 = tid; e0 < 0; e0 += kThreads * U) {
+#else
     for (int e0 = tid; e0 < Sr * kSlab; e0 += kThreads * U) {
+#endif
       cx<T> v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) v[u] = slab[min(e0 + u * kThreads, Sr * kSlab - 1)];
@@ -2153,181 +2164,256 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
     }
   }
   __syncthreads();
-  // results go to T1[|frequency| of the column][u]: what the second stage reads is then contiguous, and
+  // results go to T1[|frequency| of the column][node]: what the second stage reads is then contiguous, and
   // the 16 displacements a lane group holds for one column are adjacent here
-  double2* t1 = T1 + (int64_t)blockIdx.y * n_stored * kUpsMax;
+  double2* t1 = T1 + (int64_t)blockIdx.y * n_stored * kUpsNodes;
   // lane roles inside a step
   const int i = lane & 15, k = lane >> 4;  // A: row i, k index; B: k index, column i
   const int part = k & 1, kk_off = k >> 1;
   const int comp = (part != (i & 1)) ? 1 : 0;            // which component of R this lane feeds to B
-  const double bsign = (part == 1 && (i & 1) == 0) ? -1.0 : 1.0;
   const int bcol = 2 * (i >> 1) + comp;
-  constexpr int XN = NS >= 2 ? NS / 2 : 1;               // slabs of the shared displacement tile per wave
-  const int xs0 = NS >= 2 ? (wave >> 1) * XN : 0;
-  const bool x_on = NS >= 2 || wave < 2;                 // with one slab only two waves have a shared tile
-  const int u_tile[3] = {2 * wave, 2 * wave + 1, 8 + (wave & 1)};
-  d4 acc[2][NS], acc_x[XN];
-  double2 w[3], step2[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int u = u_tile[t] * 16 + i;
-    const double delta = (double)st.shift_s + ((double)u - (double)(n_up / 2)) / uf;
+  // wave w: displacement tile w & 1, half w >> 1 of the kk range, every slab (one rotor update then serves NS
+  // products); the two halves are added through LDS at the end
+  const int ut = wave & 1, half = wave >> 1;
+  const int all_steps = Sr / 2;  // (Sr is even)
+  const int first_steps = (all_steps + 1) / 2;
+  const int step0 = half ? first_steps : 0, nsteps = half ? all_steps - first_steps : first_steps;
+  const long long smask = (part == 1 && (i & 1) == 0) ? (long long)0x8000000000000000ull : 0ll;  // -Im R
+  d4 acc[NS];
+  double2 w, step2;
+  {
+    const double delta = (double)st.shift_s + node[ut * 16 + i];
     const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
     double sn, cs;
-    sincos(theta * (double)(kk_off - Sr / 2), &sn, &cs);
-    w[t] = mk<double>(cs, sn);
+    sincos(theta * (double)(2 * step0 + kk_off - Sr / 2), &sn, &cs);
+    w = mk<double>(cs, sn);
     sincos(2.0 * theta, &sn, &cs);
-    step2[t] = mk<double>(cs, sn);
+    step2 = mk<double>(cs, sn);
   }
 #pragma unroll
-  for (int ns = 0; ns < NS; ++ns) acc[0][ns] = acc[1][ns] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int ns = 0; ns < NS; ++ns) acc[ns] = d4{0.0, 0.0, 0.0, 0.0};
+#if defined(MS_UPS_ABLATE) && MS_UPS_ABLATE == 2  /* measurement build: no products */
+  if (nsteps > 1000000) {
+#elif defined(MS_UPS_ABLATE) && MS_UPS_ABLATE == 3  /* measurement build: an eighth of the products */
+  const int nsteps_all = nsteps;
+  if (nsteps > 0) {
+#define nsteps (nsteps_all / 8)
+#else
+  if (nsteps > 0) {
+#endif
+    const double* brow = rows + (2 * step0 + kk_off) * (2 * kSlab) + bcol;
+    double nb[NS];  // the next step's operands are read from LDS while this step's products run
 #pragma unroll
-  for (int x = 0; x < XN; ++x) acc_x[x] = d4{0.0, 0.0, 0.0, 0.0};
-  const double* brow = rows + kk_off * (2 * kSlab) + bcol;
-  for (int kk0 = 0; kk0 < Sr; kk0 += 2) {
-    double bv[NS];
+    for (int ns = 0; ns < NS; ++ns) nb[ns] = brow[ns * slab_elems];
+    for (int sidx = 0; sidx < nsteps; ++sidx) {
+      double bv[NS];
 #pragma unroll
-    for (int ns = 0; ns < NS; ++ns) bv[ns] = bsign * brow[ns * slab_elems + kk0 * (2 * kSlab)];
+      for (int ns = 0; ns < NS; ++ns) bv[ns] = __longlong_as_double(__double_as_longlong(nb[ns]) ^ smask);
+      const int nrow = 2 * min(sidx + 1, nsteps - 1);
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {  // tiles past n_up are computed too (branch-free) and not stored
-      const double av = part ? w[t].y : w[t].x;
+      for (int ns = 0; ns < NS; ++ns) nb[ns] = brow[ns * slab_elems + nrow * (2 * kSlab)];
+      const double av = part ? w.y : w.x;
 #pragma unroll
-      for (int ns = 0; ns < NS; ++ns) acc[t][ns] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[ns], acc[t][ns], 0, 0, 0);
-      w[t] = rotate(w[t], step2[t]);
+      for (int ns = 0; ns < NS; ++ns) acc[ns] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[ns], acc[ns], 0, 0, 0);
+      w = rotate(w, step2);
     }
-    const double ax = part ? w[2].y : w[2].x;
-    if (x_on) {
-#pragma unroll
-      for (int x = 0; x < XN; ++x) {
-        double b = bv[0];
-        if constexpr (NS >= 2) {
-#pragma unroll
-          for (int ns = 1; ns < NS; ++ns) b = (xs0 + x == ns) ? bv[ns] : b;
-        }
-        acc_x[x] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, b, acc_x[x], 0, 0, 0);
-      }
-    }
-    w[2] = rotate(w[2], step2[2]);
+#undef nsteps
   }
+  __syncthreads();  // every wave has read its last row: the slabs make room for the second half's sums
+  double* red = rows;  // [tile][slab][register][lane]
+  if (half == 1) {
+#pragma unroll
+    for (int ns = 0; ns < NS; ++ns)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) red[((ut * NS + ns) * 4 + g) * 64 + lane] = acc[ns][g];
+  }
+  __syncthreads();
+  if (half == 1) return;
   const int c = i >> 1, o = i & 1;
-  auto store = [&](int ut, int ns, const d4& v) {
-    if (slab0 + ns >= n_slabs) return;
+#pragma unroll
+  for (int ns = 0; ns < NS; ++ns) {
+    if (slab0 + ns >= n_slabs) continue;
     const int col = pos2stored[slab_pos[slab0 + ns] + c];
-    if (col == 0xffff) return;  // not a stored column
+    if (col == 0xffff) continue;  // not a stored column
     const int kap = stored2kappa[col];
-    if (kap == 0xffff) return;  // the second stored column of a conjugate pair: unused
+    if (kap == 0xffff) continue;  // the second stored column of a conjugate pair: unused
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int u = ut * 16 + k + 4 * g;
-      if (u < n_up) reinterpret_cast<double*>(t1 + (int64_t)kap * kUpsMax + u)[o] = v[g];
-    }
-  };
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int ns = 0; ns < NS; ++ns) store(u_tile[t], ns, acc[t][ns]);
-  if (x_on) {
-#pragma unroll
-    for (int x = 0; x < XN; ++x) store(u_tile[2], xs0 + x, acc_x[x]);
+    for (int g = 0; g < 4; ++g)
+      reinterpret_cast<double*>(t1 + (int64_t)kap * kUpsNodes + ut * 16 + k + 4 * g)[o] =
+          acc[ns][g] + red[((ut * NS + ns) * 4 + g) * 64 + lane];
   }
 }
 
-// Nyquist-row sums of the second stage: for every long-axis displacement ul,
-//   g(ul) = g1 + conj(g2),  g1 = sum over stored columns of negative frequency of V w,  g2 = the same for
-//   positive ones, V = the column's Nyquist-row value (conjugated where the stored frequency is negative),
-//   w = exp(i theta_ul kappa).  grid (pairs_in_pass); out[pair][ul] = (Re g, Im g).
-constexpr int kNyqParts = 4;  // the kappa range is cut into four, one part per 256 lanes
-__global__ __launch_bounds__(kNyqParts * 256) void k_ups_nyquist(const PairDesc* desc, const int8_t* status, int pair0,
-                                                                 int S, int L, int want_transposed,
-                                                                 const KappaEntry* __restrict__ kappa, int n_stored,
-                                                                 const double2* __restrict__ Nq,
-                                                                 const UpsState* __restrict__ ups, int n_up, double uf,
-                                                                 double2* __restrict__ gout) {
-  constexpr int kMaxKappa = 4096 / 2 + 1;
-  __shared__ double2 sV[kMaxKappa];
-  __shared__ int8_t sSign[kMaxKappa];
-  __shared__ double2 sG[kNyqParts][kUpsMax];
-  const int p = pair0 + blockIdx.x;
+// The first stage with the rows of E in registers.  Every slab of a pair is multiplied by the same E, so a workgroup
+// that takes G slabs in turn generates its part of E once (one rotor chain per lane) and the products then issue
+// back to back: in k_ups_short a rotor update (four float64 vector instructions, which do not overlap the float64
+// matrix instructions) costs as much as the product it feeds.  Eight waves: wave w takes the displacement tile w & 1
+// and quarter w >> 1 of the kk range, QS steps of two kk at most (a lane's QS values of E are QS registers pairs);
+// the quarters are added through LDS.  The next slab's values are requested before the current slab's products and
+// written to LDS while the sums of the current one are added and stored (two barriers per slab).
+// grid (ceil(n_slabs / G), pairs_in_pass), 512 lanes; LDS: one slab, the sums of the eight waves, the column tables.
+constexpr int kUpsShortThreads = 512;
+constexpr int kUpsGroupMax = 64;  // slabs a workgroup takes in turn at most
+template <typename T, int QS>
+__global__ __launch_bounds__(kUpsShortThreads) void k_ups_short_reg(const PairDesc* desc, const int8_t* status, int pair0,
+                                                                    int S, int L, int want_transposed, int Sr,
+                                                                    int64_t pair_stride,
+                                                                    const uint16_t* __restrict__ slab_pos, int n_slabs,
+                                                                    const uint16_t* __restrict__ pos2stored,
+                                                                    const uint16_t* __restrict__ stored2kappa,
+                                                                    int n_stored, const cx<T>* __restrict__ rslabs,
+                                                                    const UpsState* __restrict__ ups,
+                                                                    const double* __restrict__ node,
+                                                                    double2* __restrict__ T1, double2* __restrict__ Nq,
+                                                                    int G) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* rows = reinterpret_cast<double*>(smem_raw);  // [Sr][2 * kSlab], rows in ascending signed frequency
+  double* red = rows + (size_t)Sr * 2 * kSlab;         // [quarter][tile][register][lane]
+  // of the workgroup's slabs: first storage position, and per column the stored column (0xffff: not stored) and its
+  // |frequency| (0xffff: not stored, or the second column of a conjugate pair) - looked up once, not per slab
+  uint16_t* s_pos = reinterpret_cast<uint16_t*>(red + 8 * 4 * 64);  // [kUpsGroupMax]
+  uint16_t* s_col = s_pos + kUpsGroupMax;                           // [kUpsGroupMax][kSlab]
+  uint16_t* s_kap = s_col + kUpsGroupMax * kSlab;                   // [kUpsGroupMax][kSlab]
+  const int p = pair0 + blockIdx.y;
   if (status[p] != MISTITCH_PAIR_OK) return;
-  const PairDesc d = desc[p];
-  if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  {
+    const PairDesc& d = desc[p];
+    if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  }
   const UpsState st = ups[p];
   if (!st.valid) return;
-  const int tid = threadIdx.x, ul = tid & 255, part = tid >> 8;
-  const double2* nq = Nq + (int64_t)blockIdx.x * n_stored;
-  const int n_kappa = L / 2 + 1;
-  for (int e = tid; e < n_kappa; e += kNyqParts * 256) {
-    const KappaEntry ke = kappa[e];
-    double2 v = nq[ke.stored];
-    if (ke.sign < 0) v.y = -v.y;
-    if (ke.self) v = mk<double>(0.0, 0.0);  // self-conjugate columns have no partner to correct
-    sV[e] = v;
-    sSign[e] = ke.sign;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const cx<T>* Rs = rslabs + (int64_t)blockIdx.y * pair_stride;
+  const int64_t sp = slab_pitch(Sr);
+  const int slab0 = blockIdx.x * G, slab1 = min(slab0 + G, n_slabs);
+  double2* t1 = T1 + (int64_t)blockIdx.y * n_stored * kUpsNodes;
+  // lane roles inside a step (see k_ups_short)
+  const int i = lane & 15, k = lane >> 4;
+  const int part = k & 1, kk_off = k >> 1;
+  const int comp = (part != (i & 1)) ? 1 : 0;
+  const int bcol = 2 * (i >> 1) + comp;
+  const long long smask = (part == 1 && (i & 1) == 0) ? (long long)0x8000000000000000ull : 0ll;  // -Im R
+  const int ut = wave & 1, quarter = wave >> 1;
+  const int all_steps = Sr / 2;  // (Sr is even)
+  const int per = (all_steps + 3) / 4;  // <= QS, checked by the host
+  const int step0 = min(all_steps, quarter * per), nsteps = min(all_steps, step0 + per) - step0;
+  constexpr int U = 8 * QS * kSlab / kUpsShortThreads;  // loads per lane and slab (Sr <= 8 QS)
+  cx<T> pre[U];
+  for (int e = tid; e < (slab1 - slab0) * kSlab; e += kUpsShortThreads) {
+    const int pos = slab_pos[slab0 + e / kSlab];
+    const int col = pos2stored[pos + e % kSlab];
+    if (e % kSlab == 0) s_pos[e / kSlab] = (uint16_t)pos;
+    s_col[e] = (uint16_t)col;
+    s_kap[e] = col == 0xffff ? (uint16_t)0xffff : stored2kappa[col];
   }
-  __syncthreads();
-  const int per = (n_kappa + kNyqParts - 1) / kNyqParts;
-  const int k_begin = part * per, k_end = min(n_kappa, k_begin + per);
-  if (ul < n_up) {
-    const double delta_l = (double)st.shift_l + ((double)ul - (double)(n_up / 2)) / uf;
-    const double theta = 2.0 * 3.14159265358979323846 * delta_l / (double)L;
-    double sn, cs;
-    sincos(theta, &sn, &cs);
-    const double2 step = mk<double>(cs, sn);
-    sincos(theta * (double)k_begin, &sn, &cs);
-    double2 w = mk<double>(cs, sn), g1 = mk<double>(0.0, 0.0), g2 = mk<double>(0.0, 0.0);
-    for (int j = k_begin; j < k_end; ++j) {
-      const double2 vw = cmul(sV[j], w);
-      if (sSign[j] < 0) {
-        g1.x += vw.x;
-        g1.y += vw.y;
-      } else {
-        g2.x += vw.x;
-        g2.y += vw.y;
-      }
-      w = cmul(w, step);
-    }
-    sG[part][ul] = mk<double>(g1.x + g2.x, g1.y - g2.y);
-  }
-  __syncthreads();
-  if (part == 0 && ul < n_up) {
-    double2 g = sG[0][ul];
+  auto fetch = [&](int sl, int pos) {
+#if defined(MS_UPS_ABLATE) && MS_UPS_ABLATE == 1  /* measurement build: one slab of every pair is read over and over */
+    pos = 0;
+#endif
+    const cx<T>* slab = Rs + (pos / kSlab) * sp;
 #pragma unroll
-    for (int q = 1; q < kNyqParts; ++q) {
-      g.x += sG[q][ul].x;
-      g.y += sG[q][ul].y;
+    for (int u = 0; u < U; ++u) pre[u] = slab[min(tid + u * kUpsShortThreads, Sr * kSlab - 1)];
+  };
+  fetch(slab0, slab_pos[slab0]);
+  double av[QS];
+  {
+    const double delta = (double)st.shift_s + node[ut * 16 + i];
+    const double theta = 2.0 * 3.14159265358979323846 * delta / (double)S;
+    double sn, cs;
+    sincos(theta * (double)(2 * step0 + kk_off - Sr / 2), &sn, &cs);
+    double2 w = mk<double>(cs, sn);
+    sincos(2.0 * theta, &sn, &cs);
+    const double2 step2 = mk<double>(cs, sn);
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      av[q] = part ? w.y : w.x;
+      w = rotate(w, step2);
     }
-    gout[(int64_t)blockIdx.x * kUpsMax + ul] = g;
+  }
+  const double* brow = rows + (2 * step0 + kk_off) * (2 * kSlab) + bcol;
+  const int c = i >> 1, o = i & 1;
+  auto spread = [&](int sl) {  // the fetched slab into LDS, its Nyquist row (signed frequency -S/2, the first row) to Nq
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = tid + u * kUpsShortThreads;
+      if (e < Sr * kSlab) {
+        rows[2 * e] = (double)pre[u].x;
+        rows[2 * e + 1] = (double)pre[u].y;
+      }
+    }
+    if (tid < kSlab) {
+      const int col = s_col[(sl - slab0) * kSlab + tid];
+      if (col != 0xffff) Nq[(int64_t)blockIdx.y * n_stored + col] = mk<double>((double)pre[0].x, (double)pre[0].y);
+    }
+  };
+  __syncthreads();  // the tables
+  spread(slab0);
+  __syncthreads();
+  for (int sl = slab0; sl < slab1; ++sl) {
+    if (sl + 1 < slab1) fetch(sl + 1, s_pos[sl + 1 - slab0]);  // in flight during the products
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#if defined(MS_UPS_ABLATE) && MS_UPS_ABLATE == 2  /* measurement build: no products */
+    if (nsteps > 1000000)
+#endif
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+      if (q < nsteps) {  // (the same for every lane of the wave)
+        const double b = __longlong_as_double(__double_as_longlong(brow[2 * q * (2 * kSlab)]) ^ smask);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], b, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) red[((quarter * 2 + ut) * 4 + g) * 64 + lane] = acc[g];
+    __syncthreads();  // every wave has read its last row of the slab and written its sums
+    // (the next slab first: its values were requested a whole round of products ago, and waiting for them after
+    // the stores below would wait for those stores as well)
+    if (sl + 1 < slab1) spread(sl + 1);
+    {
+      // wave (tile, quarter) adds the four quarters of result register g = quarter of its tile and stores it
+      const int g = quarter;
+      const int kap = s_kap[(sl - slab0) * kSlab + c];
+      double v = red[((0 * 2 + ut) * 4 + g) * 64 + lane];
+#pragma unroll
+      for (int qq = 1; qq < 4; ++qq) v += red[((qq * 2 + ut) * 4 + g) * 64 + lane];
+      if (kap != 0xffff) reinterpret_cast<double*>(t1 + (int64_t)kap * kUpsNodes + ut * 16 + k + 4 * g)[o] = v;
+    }
+    __syncthreads();  // the next slab is in place, the sums have been consumed
   }
 }
 
 // Second stage on the matrix cores.  With Y[us][kappa] the first-stage value of the stored column of
 // |frequency| kappa (conjugated where that column's frequency is negative, doubled unless it is its own
 // partner), Re CC[us][ul] = sum_kappa Re(Y w), w = exp(i theta_ul kappa), is a real product C = A B with
-//   A[us][2 kappa + p] = p ? -Im Y : Re Y        (staged in LDS, 64 kappa at a time)
-//   B[2 kappa + p][ul] = p ? Im w : Re w         (generated: one rotor per lane and column tile)
+//   A[us][2 kappa + p] = p ? -Im Y : Re Y        (staged in LDS, 32 kappa at a time)
+//   B[2 kappa + p][ul] = p ? Im w : Re w         (generated: one rotor per lane)
 // run as v_mfma_f64_16x16x4_f64 steps of two kappa (lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15];
 // result register g of lane l is C[(l >> 4) + 4 g][l & 15]).  The imaginary part exists only for the two
-// self-conjugate columns and is added, with the Nyquist-row term, when the magnitudes are formed.
-// grid (ceil(n_up / kUpsRows), pairs_in_pass): a workgroup owns kUpsRows = 80 short-axis displacements
-// (five row tiles) and all ten column tiles.  Emits the block's largest
-// |CC|^2, first in the row-major order of the IMAGE orientation on ties.
-// The 10 x 5 result tiles of a workgroup are dealt to its four waves as evenly as a shared rotor allows:
-// wave w takes column tiles 2w and 2w + 1 with all five row tiles, and of column tile 8 + (w & 1) the row
-// tiles {0, 1, 2} (w < 2) or {3, 4}: 13 or 12 products per step and three rotor updates (the rotors are
-// float64 vector work, which competes with the float64 matrix instructions for the same units).
-__global__ __launch_bounds__(kThreads) void k_ups_long(const PairDesc* desc, const int8_t* status, int pair0, int S, int L,
-                                                       int want_transposed, const KappaEntry* __restrict__ kappa,
-                                                       int n_stored, const double2* __restrict__ T1,
-                                                       const double2* __restrict__ gin,
-                                                       const UpsState* __restrict__ ups, int n_up, double uf,
-                                                       Peak* partial_ups, int n_row_blocks) {
-  constexpr int kChunk = 32;                 // kappa per staging round
-  constexpr int kRowTiles = kUpsRows / 16;   // 5
-  static_assert(kRowTiles == 5 && kUpsMax <= 160 && kThreads == 256, "tile assignment below");
-  __shared__ double sA[kChunk][kUpsRows][2];  // (Re Y, -Im Y)
-  __shared__ double2 sSelf[2][kUpsRows];      // Y of the self-conjugate columns kappa = 0 and kappa = L / 2
-  __shared__ KappaEntry sK[4096 / 2 + 1];
-  __shared__ Peak red[kThreads / 64];
+// self-conjugate columns.
+// grid (kUpsLongParts, pairs_in_pass), five waves: a workgroup sums one part of the kappa range (a pass of 128
+// pairs would otherwise be 128 workgroups, each a chain of 500 dependent steps); waves 0-3 take the 2 x 2 result
+// tiles of the 32 x 32 node displacements (wave w: column tile w & 1, row tile w >> 1) and write the part's sums to
+// ccn_part[pair][part][us][ul].  Wave 4 forms the part's Nyquist-row sums for every long-axis node ul,
+//   g(ul) = g1 + conj(g2),  g1 = sum over stored columns of negative frequency of V w,  g2 = the same for
+//   positive ones, V = the column's Nyquist-row value (conjugated where the stored frequency is negative),
+// into g_part[pair][part][ul] (lanes: node ul = lane & 31, half lane >> 5 of each round's 32 kappa).
+// k_ups_interp adds the parts in a fixed order.
+constexpr int kUpsLongParts = 8;
+constexpr int kUpsLongThreads = kThreads + 64;
+__global__ __launch_bounds__(kUpsLongThreads) void k_ups_long(const PairDesc* desc, const int8_t* status, int pair0, int S,
+                                                              int L, int want_transposed,
+                                                              const KappaEntry* __restrict__ kappa, int n_stored,
+                                                              const double2* __restrict__ T1,
+                                                              const double2* __restrict__ Nq,
+                                                              const UpsState* __restrict__ ups,
+                                                              const double* __restrict__ node,
+                                                              double2* __restrict__ ccn_part,
+                                                              double2* __restrict__ g_part) {
+  constexpr int kChunk = 32;  // kappa per staging round
+  static_assert(kUpsNodes == 32 && kThreads == 256, "tile assignment below");
+  __shared__ double sA[kChunk][kUpsNodes][2];  // (Re Y, -Im Y)
+  __shared__ double2 sSelf[2][kUpsNodes];      // Y of the self-conjugate columns kappa = 0 and kappa = L / 2
+  __shared__ double2 sV[kChunk];               // the round's Nyquist-row values
+  __shared__ int8_t sSign[kChunk];
   const int p = pair0 + blockIdx.y;
   if (status[p] != MISTITCH_PAIR_OK) return;
   const PairDesc d = desc[p];
@@ -2335,138 +2421,236 @@ __global__ __launch_bounds__(kThreads) void k_ups_long(const PairDesc* desc, con
   const UpsState st = ups[p];
   if (!st.valid) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int us0 = blockIdx.x * kUpsRows;
-  const int nrows = min(kUpsRows, n_up - us0);
-  const double2* t1 = T1 + (int64_t)blockIdx.y * n_stored * kUpsMax;  // [kappa][u]
+  const double2* t1 = T1 + (int64_t)blockIdx.y * n_stored * kUpsNodes;  // [kappa][node]
+  const double2* nq = Nq + (int64_t)blockIdx.y * n_stored;
   const int n_kappa = L / 2 + 1;
+  // this part's kappa range, of even length (a step takes two kappa); a part past the end sums nothing and writes zeros
+  const int per = ((n_kappa + kUpsLongParts - 1) / kUpsLongParts + 1) & ~1;
+  const int k_lo = min(n_kappa, (int)blockIdx.x * per), k_hi = min(n_kappa, k_lo + per);
   const int i = lane & 15, k = lane >> 4;
   const int part = k & 1, kk_off = k >> 1;
-  const bool low = wave < 2;  // which row tiles of the shared column tile this wave takes
-  const int col_tile[3] = {2 * wave, 2 * wave + 1, 8 + (wave & 1)};
-  // rotors of this lane's column in each of the wave's column tiles
-  double2 w[3], step2[3];
-  d4 acc[2][kRowTiles], acc_x[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int ul = col_tile[t] * 16 + i;
-    const double delta_l = (double)st.shift_l + ((double)ul - (double)(n_up / 2)) / uf;
-    const double theta = 2.0 * 3.14159265358979323846 * delta_l / (double)L;
+  const int ct = wave & 1, rt = (wave >> 1) & 1;
+  const bool nyq = wave == 4;
+  const int ul = nyq ? (lane & 31) : ct * 16 + i;
+  const int nyq_half = lane >> 5;
+  const double delta_l = (double)st.shift_l + node[ul];
+  const double theta = 2.0 * 3.14159265358979323846 * delta_l / (double)L;
+  double2 w, step2, jump = mk<double>(1.0, 0.0);
+  {
     double sn, cs;
-    sincos(theta * (double)kk_off, &sn, &cs);
-    w[t] = mk<double>(cs, sn);
-    sincos(2.0 * theta, &sn, &cs);
-    step2[t] = mk<double>(cs, sn);
-    acc_x[t] = d4{0.0, 0.0, 0.0, 0.0};
+    sincos(theta * (double)(k_lo + (nyq ? nyq_half * (kChunk / 2) : kk_off)), &sn, &cs);
+    w = mk<double>(cs, sn);
+    sincos((nyq ? 1.0 : 2.0) * theta, &sn, &cs);
+    step2 = mk<double>(cs, sn);
+    if (nyq) {  // from the end of this half of a round to the same half of the next
+      sincos(theta * (double)(kChunk / 2), &sn, &cs);
+      jump = mk<double>(cs, sn);
+    }
   }
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int a = 0; a < kRowTiles; ++a) acc[t][a] = d4{0.0, 0.0, 0.0, 0.0};
-  // staging: element e of a round is (kappa j = e / kUpsRows, row r = e % kUpsRows)
-  constexpr int kPer = kChunk * kUpsRows / kThreads;  // 10 elements per lane and round
-  static_assert(kChunk * kUpsRows % kThreads == 0 && kChunk % 2 == 0, "staging pattern");
-  // The column table sits in LDS so that the loads of the next round can be issued (into registers)
-  // before the products of this round and completed after them; conjugation and scaling wait
-  // until the values are written to LDS.
-  for (int e = tid; e < n_kappa; e += kThreads) sK[e] = kappa[e];
-  if (tid < 2 * kUpsRows) sSelf[tid / kUpsRows][tid % kUpsRows] = mk<double>(0.0, 0.0);
-  __syncthreads();
+  d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+  double2 g1 = mk<double>(0.0, 0.0), g2 = mk<double>(0.0, 0.0);
+  // staging: element e of a round is (kappa j = e / kUpsNodes, node r = e % kUpsNodes), contiguous in T1
+  constexpr int kPer = kChunk * kUpsNodes / kThreads;  // 4 elements per lane and round
+  static_assert(kChunk * kUpsNodes % kThreads == 0 && kChunk % 2 == 0 && kChunk <= 64, "staging pattern");
+  if (tid < 2 * kUpsNodes) sSelf[tid / kUpsNodes][tid % kUpsNodes] = mk<double>(0.0, 0.0);
+  // The loads of the next round are issued (into registers) before the products of this round and completed
+  // after them; conjugation and scaling wait until the values are written to LDS.
   double2 pre[kPer];
+  KappaEntry pre_k[kPer];
+  double2 pre_v = mk<double>(0.0, 0.0);
+  KappaEntry pre_vk{0, 1, 1};
   auto fetch = [&](int k0) {
+    if (!nyq) {
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-      const int e = tid + q * kThreads, j = e / kUpsRows, r = e - j * kUpsRows;
-      const int kap = min(k0 + j, n_kappa - 1);
-      pre[q] = t1[(int64_t)kap * kUpsMax + us0 + min(r, nrows - 1)];
+      for (int q = 0; q < kPer; ++q) {
+        const int e = tid + q * kThreads, j = e / kUpsNodes, r = e - j * kUpsNodes;
+        const int kap = min(k0 + j, n_kappa - 1);
+        pre[q] = t1[(int64_t)kap * kUpsNodes + r];
+        pre_k[q] = kappa[kap];
+      }
+    } else if (lane < kChunk) {
+      pre_vk = kappa[min(k0 + lane, n_kappa - 1)];
+      pre_v = nq[pre_vk.stored];
     }
   };
   auto stage = [&](int k0) {
+    if (!nyq) {
 #pragma unroll
-    for (int q = 0; q < kPer; ++q) {
-      const int e = tid + q * kThreads, j = e / kUpsRows, r = e - j * kUpsRows;
-      const int kap = k0 + j;
-      double2 x = mk<double>(0.0, 0.0);
-      if (kap < n_kappa && r < nrows) {
-        const KappaEntry ke = sK[kap];
-        x = pre[q];
-        if (ke.sign < 0) x.y = -x.y;
-        if (ke.self) {
-          const double sgn = ke.sign < 0 ? -1.0 : 1.0;  // Im(Y w) carries the sign of the stored frequency
-          sSelf[kap == 0 ? 0 : 1][r] = mk<double>(sgn * x.x, sgn * x.y);
-        } else {
-          x.x *= 2.0;
-          x.y *= 2.0;
+      for (int q = 0; q < kPer; ++q) {
+        const int e = tid + q * kThreads, j = e / kUpsNodes, r = e - j * kUpsNodes;
+        const int kap = k0 + j;
+        double2 x = mk<double>(0.0, 0.0);
+        if (kap < k_hi) {
+          const KappaEntry ke = pre_k[q];
+          x = pre[q];
+          if (ke.sign < 0) x.y = -x.y;
+          if (ke.self) {
+            const double sgn = ke.sign < 0 ? -1.0 : 1.0;  // Im(Y w) carries the sign of the stored frequency
+            sSelf[kap == 0 ? 0 : 1][r] = mk<double>(sgn * x.x, sgn * x.y);
+          } else {
+            x.x *= 2.0;
+            x.y *= 2.0;
+          }
         }
+        sA[j][r][0] = x.x;
+        sA[j][r][1] = -x.y;
       }
-      sA[j][r][0] = x.x;
-      sA[j][r][1] = -x.y;
+    } else if (lane < kChunk) {
+      double2 v = pre_v;
+      if (pre_vk.sign < 0) v.y = -v.y;
+      if (pre_vk.self || k0 + lane >= k_hi) v = mk<double>(0.0, 0.0);  // self-conjugate columns have no partner to correct
+      sV[lane] = v;
+      sSign[lane] = pre_vk.sign;
     }
   };
-  fetch(0);
-  for (int k0 = 0; k0 < n_kappa; k0 += kChunk) {
+  if (k_lo < k_hi) fetch(k_lo);
+  for (int k0 = k_lo; k0 < k_hi; k0 += kChunk) {
     __syncthreads();  // the previous round has been consumed
     stage(k0);
     __syncthreads();
-    if (k0 + kChunk < n_kappa) fetch(k0 + kChunk);  // in flight during the products
-    const int nsteps = (min(kChunk, n_kappa - k0) + 1) / 2;
-    double nxt[kRowTiles];  // the next step's operands are read from LDS while this step's products run
-#pragma unroll
-    for (int a = 0; a < kRowTiles; ++a) nxt[a] = sA[kk_off][16 * a + i][part];
-    for (int sidx = 0; sidx < nsteps; ++sidx) {
-      double av[kRowTiles];
-#pragma unroll
-      for (int a = 0; a < kRowTiles; ++a) av[a] = nxt[a];
-      const int srow = min(2 * (sidx + 1), kChunk - 2) + kk_off;
-#pragma unroll
-      for (int a = 0; a < kRowTiles; ++a) nxt[a] = sA[srow][16 * a + i][part];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {  // columns past n_up are computed too (branch-free) and not used
-        const double bv = part ? w[t].y : w[t].x;
-#pragma unroll
-        for (int a = 0; a < kRowTiles; ++a) acc[t][a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv, acc[t][a], 0, 0, 0);
-        w[t] = rotate(w[t], step2[t]);
+    if (k0 + kChunk < k_hi) fetch(k0 + kChunk);  // in flight during the products
+    if (!nyq) {
+      const int nsteps = (min(kChunk, k_hi - k0) + 1) / 2;
+      double nxt = sA[kk_off][16 * rt + i][part];  // the next step's operand is read from LDS while this step's product runs
+      for (int sidx = 0; sidx < nsteps; ++sidx) {
+        const double av = nxt;
+        nxt = sA[min(2 * (sidx + 1), kChunk - 2) + kk_off][16 * rt + i][part];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, part ? w.y : w.x, acc, 0, 0, 0);
+        w = rotate(w, step2);
       }
-      const double bx = part ? w[2].y : w[2].x;
-      acc_x[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(low ? av[0] : av[3], bx, acc_x[0], 0, 0, 0);
-      acc_x[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(low ? av[1] : av[4], bx, acc_x[1], 0, 0, 0);
-      if (low) acc_x[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2], bx, acc_x[2], 0, 0, 0);
-      w[2] = rotate(w[2], step2[2]);
+      // (a round cut short by k_hi is the last one: the rotor is not used again)
+    } else {
+#pragma unroll 4
+      for (int j = 0; j < kChunk / 2; ++j) {  // values past k_hi are zero
+        const int e = nyq_half * (kChunk / 2) + j;
+        const double2 vw = cmul(sV[e], w);
+        if (sSign[e] < 0) {
+          g1.x += vw.x;
+          g1.y += vw.y;
+        } else {
+          g2.x += vw.x;
+          g2.y += vw.y;
+        }
+        w = cmul(w, step2);
+      }
+      w = cmul(w, jump);
     }
   }
   __syncthreads();  // sSelf is complete
-  Peak mine{-INFINITY, -1, -1};
-  const double2* g = gin + (int64_t)blockIdx.y * kUpsMax;
-  // one result tile: columns ct * 16 + (lane & 15), rows rt * 16 + (lane >> 4) + 4 q
-  auto finish = [&](int ct, int rt, const d4& c) {
-    const int ul = ct * 16 + i;
-    if (ul >= n_up) return;
-    const double delta_l = (double)st.shift_l + ((double)ul - (double)(n_up / 2)) / uf;
-    double sn, cs;
-    sincospi(delta_l, &sn, &cs);  // w at kappa = L / 2 (kappa = 0: w = 1)
-    const double2 gv = g[ul];
+  if (nyq) {
+    double2 g = mk<double>(g1.x + g2.x, g1.y - g2.y);
+    g.x += __shfl_xor(g.x, 32);
+    g.y += __shfl_xor(g.y, 32);
+    if (lane < kUpsNodes) g_part[((int64_t)blockIdx.y * kUpsLongParts + blockIdx.x) * kUpsNodes + ul] = g;
+    return;
+  }
+  // the wave's result tile: column ct * 16 + (lane & 15), rows rt * 16 + (lane >> 4) + 4 q
+  double sn, cs;
+  sincospi(delta_l, &sn, &cs);  // w at kappa = L / 2 (kappa = 0: w = 1)
+  double2* out = ccn_part + ((int64_t)blockIdx.y * kUpsLongParts + blockIdx.x) * kUpsNodes * kUpsNodes;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int r = 16 * rt + k + 4 * q;
-      if (r < nrows) {
-        const int us = us0 + r;
-        const double2 y0 = sSelf[0][r], yh = sSelf[1][r];
-        const double im = y0.y + (yh.x * sn + yh.y * cs);
-        const double delta_s = (double)st.shift_s + ((double)us - (double)(n_up / 2)) / uf;
-        const double s2 = 2.0 * sinpi(delta_s);
-        const double cr = c[q] + s2 * gv.y, ci = im - s2 * gv.x;
-        const double mag2 = cr * cr + ci * ci;
-        const int key = d.transposed ? ul * n_up + us : us * n_up + ul;
-        if (first_better(mag2, key, mine.val, mine.key)) mine = Peak{mag2, key, 0};
+  for (int q = 0; q < 4; ++q) {
+    const int us = 16 * rt + k + 4 * q;
+    const double2 y0 = sSelf[0][us], yh = sSelf[1][us];
+    out[us * kUpsNodes + ul] = mk<double>(acc[q], y0.y + (yh.x * sn + yh.y * cs));
+  }
+}
+
+// The node values carried to the upsampled grid, CC[us][ul] = sum_js sum_jl P[us][js] C[js][jl] P[ul][jl], and
+// the largest |CC|^2 of the block, first in the row-major order of the IMAGE orientation on ties.  C = the sum of the
+// parts k_ups_long wrote plus the Nyquist-row term (2 sin(pi ds) g.y, -2 sin(pi ds) g.x), g the summed g_part.
+// P[kUpsMax][kUpsNodes] row-major, Pt its transpose.  grid (ceil(n_up / 16), pairs_in_pass): a workgroup owns 16 rows
+// of the grid and all its columns.  Both products run on the matrix cores (lane l holds A[l & 15][l >> 4] and
+// B[l >> 4][l & 15]; result register g of lane l is C[(l >> 4) + 4 g][l & 15]): first G = P_rows C (wave w: the real
+// or imaginary parts, w >> 1, of the node columns 16 (w & 1) ...), then CC = G Pt (wave w: column tiles w, w + 4, w + 8).
+__global__ __launch_bounds__(kThreads) void k_ups_interp(const PairDesc* desc, const int8_t* status, int pair0, int S, int L,
+                                                         int want_transposed, const double2* __restrict__ ccn_part,
+                                                         const double2* __restrict__ g_part,
+                                                         const double* __restrict__ node, const double* __restrict__ P,
+                                                         const double* __restrict__ Pt,
+                                                         const UpsState* __restrict__ ups, int n_up, Peak* partial_ups,
+                                                         int n_row_blocks) {
+  __shared__ double sC[2][kUpsNodes][kUpsNodes];  // node values [re | im][js][jl]
+  __shared__ double sG[2][16][kUpsNodes + 1];     // the block's rows against node columns [re | im][row][jl]
+  __shared__ Peak red[kThreads / 64];
+  static_assert(kUpsNodes == 32 && kThreads == 256 && kUpsMax <= 12 * 16, "tile assignment below");
+  const int p = pair0 + blockIdx.y;
+  if (status[p] != MISTITCH_PAIR_OK) return;
+  const PairDesc d = desc[p];
+  if (d.S != S || d.L != L || (want_transposed >= 0 && d.transposed != want_transposed)) return;
+  const UpsState st = ups[p];
+  if (!st.valid) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int us0 = blockIdx.x * 16;
+  {
+    const int jl = tid % kUpsNodes;
+    double2 g = mk<double>(0.0, 0.0);
+#pragma unroll
+    for (int q = 0; q < kUpsLongParts; ++q) {
+      const double2 v = g_part[((int64_t)blockIdx.y * kUpsLongParts + q) * kUpsNodes + jl];
+      g.x += v.x;
+      g.y += v.y;
+    }
+#pragma unroll
+    for (int r = 0; r < kUpsNodes * kUpsNodes / kThreads; ++r) {
+      const int js = tid / kUpsNodes + r * (kThreads / kUpsNodes);
+      double2 c = mk<double>(0.0, 0.0);
+#pragma unroll
+      for (int q = 0; q < kUpsLongParts; ++q) {
+        const double2 v = ccn_part[((int64_t)blockIdx.y * kUpsLongParts + q) * kUpsNodes * kUpsNodes + js * kUpsNodes + jl];
+        c.x += v.x;
+        c.y += v.y;
+      }
+      const double s2 = 2.0 * sinpi((double)st.shift_s + node[js]);
+      sC[0][js][jl] = c.x + s2 * g.y;
+      sC[1][js][jl] = c.y - s2 * g.x;
+    }
+  }
+  __syncthreads();
+  const int i = lane & 15, k = lane >> 4;
+  {
+    const int comp = wave >> 1, c0 = 16 * (wave & 1);
+    const double* prow = P + (int64_t)min(us0 + i, n_up - 1) * kUpsNodes;
+    d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < kUpsNodes / 4; ++s4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(prow[4 * s4 + k], sC[comp][4 * s4 + k][c0 + i], acc, 0, 0, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) sG[comp][k + 4 * g][c0 + i] = acc[g];
+  }
+  __syncthreads();
+  double a_re[kUpsNodes / 4], a_im[kUpsNodes / 4];
+#pragma unroll
+  for (int s4 = 0; s4 < kUpsNodes / 4; ++s4) {
+    a_re[s4] = sG[0][i][4 * s4 + k];
+    a_im[s4] = sG[1][i][4 * s4 + k];
+  }
+  Peak mine{-INFINITY, -1, -1};
+  const int n_ct = (n_up + 15) / 16;
+  for (int ct = wave; ct < n_ct; ct += kThreads / 64) {
+    const int ul = ct * 16 + i;
+    const double* pcol = Pt + min(ul, n_up - 1);
+    double b[kUpsNodes / 4];
+#pragma unroll
+    for (int s4 = 0; s4 < kUpsNodes / 4; ++s4) b[s4] = pcol[(4 * s4 + k) * kUpsMax];
+    d4 cr = d4{0.0, 0.0, 0.0, 0.0}, ci = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s4 = 0; s4 < kUpsNodes / 4; ++s4) {
+      cr = __builtin_amdgcn_mfma_f64_16x16x4f64(a_re[s4], b[s4], cr, 0, 0, 0);
+      ci = __builtin_amdgcn_mfma_f64_16x16x4f64(a_im[s4], b[s4], ci, 0, 0, 0);
+    }
+    if (ul < n_up) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int us = us0 + k + 4 * g;
+        if (us < n_up) {
+          const double mag2 = cr[g] * cr[g] + ci[g] * ci[g];
+          const int key = d.transposed ? ul * n_up + us : us * n_up + ul;
+          if (first_better(mag2, key, mine.val, mine.key)) mine = Peak{mag2, key, 0};
+        }
       }
     }
-  };
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int a = 0; a < kRowTiles; ++a) finish(col_tile[t], a, acc[t][a]);
-  finish(col_tile[2], low ? 0 : 3, acc_x[0]);
-  finish(col_tile[2], low ? 1 : 4, acc_x[1]);
-  if (low) finish(col_tile[2], 2, acc_x[2]);
+  }
   const Peak best = block_argmax_first(mine, red);
   if (tid == 0) partial_ups[(int64_t)blockIdx.y * n_row_blocks + blockIdx.x] = best;
 }
@@ -3835,7 +4019,8 @@ static int make_gen_shape(mistitch_ctx* ctx, int S, int L, GenShape* g) {
       for (int c = 0; c < n_cols8; ++c) ident[c] = (uint16_t)c;
       for (int c = 0; c < n_cols; ++c) {
         s2k[c] = (uint16_t)c;
-        kap[c] = KappaEntry{(uint16_t)c, 1, (int8_t)((c == 0 || (L % 2 == 0 && c == L / 2)) ? 1 : 0)};
+        const bool nyquist = L % 2 == 0 && c == L / 2;  // counts as the negative frequency -L / 2, as numpy.fft.fftfreq does
+        kap[c] = KappaEntry{(uint16_t)c, (int8_t)(nyquist ? -1 : 1), (int8_t)((c == 0 || nyquist) ? 1 : 0)};
       }
       const size_t b1 = (slabs.size() * 2 + 15) / 16 * 16, b2 = ((size_t)n_cols8 * 2 + 15) / 16 * 16;
       const size_t b4 = kap.size() * sizeof(KappaEntry);
@@ -3925,10 +4110,67 @@ struct RegWorkspace {
   Peak* partial_ups = nullptr;    // [chunk][n_row_blocks]
   int n_row_blocks = 0;
   double2* nq = nullptr;          // [chunk][n_stored_max]
-  double2* gxy = nullptr;         // [chunk][kUpsMax] Nyquist-row sums per long-axis displacement
-  double2* t1 = nullptr;          // [chunk][n_stored_max][kUpsMax]: first-stage results by |frequency| and displacement
+  double2* gxy = nullptr;         // [chunk][kUpsLongParts][kUpsNodes] Nyquist-row sums per long-axis node displacement, by part of the column range
+  double2* t1 = nullptr;          // [chunk][n_stored_max][kUpsNodes]: first-stage results by |frequency| and node
+  double2* ccn = nullptr;         // [chunk][kUpsLongParts][kUpsNodes][kUpsNodes]: the correlation at the node displacements, by part
+  const double* ups_node = nullptr;  // [kUpsNodes] node displacements relative to the coarse shift, pixels
+  const double* ups_p = nullptr;     // [kUpsMax][kUpsNodes] interpolation matrix, nodes -> upsampled grid
+  const double* ups_pt = nullptr;    // [kUpsNodes][kUpsMax] its transpose
   int n_stored_max = 0;
 };
+
+// Node displacements and interpolation matrix of the subpixel stage for one upsample factor (device tables, built on
+// first use).  The grid offsets are o_u = (u - floor(n_up / 2)) / uf, u < n_up; on the interval they span, scaled
+// to [-1, 1], the nodes are the Chebyshev points of the first kind t_j = cos(pi (2 j + 1) / (2 M)) and
+// P[u][j] = (w_j / (x_u - t_j)) / sum_k (w_k / (x_u - t_k)), w_j = (-1)^j sin(pi (2 j + 1) / (2 M)), is the barycentric
+// form of the interpolating polynomial's value at x_u.
+static int get_ups_grid(mistitch_ctx* ctx, int uf, int n_up, RegWorkspace* ws) {
+  auto it = ctx->ups_grid_tables.find(uf);
+  if (it == ctx->ups_grid_tables.end()) {
+    constexpr int M = kUpsNodes;
+    const long double pi = 3.141592653589793238462643383279502884L;
+    std::vector<double> blob((size_t)M + 2 * (size_t)kUpsMax * M, 0.0);
+    double* node = blob.data();
+    double* P = node + M;
+    double* Pt = P + (size_t)kUpsMax * M;
+    const long double centre = ((long double)(n_up - 1) / 2 - (long double)(n_up / 2)) / uf;
+    const long double half = (long double)(n_up - 1) / (2 * (long double)uf);
+    long double t[M], wgt[M];
+    for (int j = 0; j < M; ++j) {
+      t[j] = cosl(pi * (2 * j + 1) / (2 * M));
+      wgt[j] = ((j & 1) ? -1 : 1) * sinl(pi * (2 * j + 1) / (2 * M));
+      node[j] = (double)(centre + half * t[j]);
+    }
+    for (int u = 0; u < n_up; ++u) {
+      const long double x = (2 * (long double)u - (n_up - 1)) / (long double)(n_up - 1);
+      int hit = -1;
+      long double q[M], sum = 0;
+      for (int j = 0; j < M; ++j) {
+        if (x == t[j]) {
+          hit = j;
+          break;
+        }
+        q[j] = wgt[j] / (x - t[j]);
+        sum += q[j];
+      }
+      for (int j = 0; j < M; ++j) {
+        const double v = hit >= 0 ? (j == hit ? 1.0 : 0.0) : (double)(q[j] / sum);
+        P[(size_t)u * M + j] = v;
+        Pt[(size_t)j * kUpsMax + u] = v;
+      }
+    }
+    void* dev = nullptr;
+    MS_HIP(hipMalloc(&dev, blob.size() * sizeof(double)));
+    ctx->shape_allocs.push_back(dev);
+    MS_HIP(hipMemcpy(dev, blob.data(), blob.size() * sizeof(double), hipMemcpyHostToDevice));
+    it = ctx->ups_grid_tables.emplace(uf, dev).first;
+  }
+  const double* base = reinterpret_cast<const double*>(it->second);
+  ws->ups_node = base;
+  ws->ups_p = base + kUpsNodes;
+  ws->ups_pt = base + kUpsNodes + (size_t)kUpsMax * kUpsNodes;
+  return MISTITCH_OK;
+}
 
 // Carve the subpixel buffers out of the context's workspace.
 static int reserve_subpixel(mistitch_ctx* ctx, int n_pairs, int chunk, int abs_stride, int n_stored_max, int uf,
@@ -3942,10 +4184,12 @@ static int reserve_subpixel(mistitch_ctx* ctx, int n_pairs, int chunk, int abs_s
   const size_t b_abs = pad((size_t)chunk * abs_stride * sizeof(Peak));
   const size_t b_pu = pad((size_t)chunk * n_row_blocks * sizeof(Peak));
   const size_t b_nq = pad((size_t)chunk * n_stored_max * sizeof(double2));
-  const size_t b_g = pad((size_t)chunk * kUpsMax * sizeof(double2));
-  const size_t b_t1 = pad((size_t)chunk * kUpsMax * n_stored_max * sizeof(double2));
+  const size_t b_g = pad((size_t)chunk * kUpsLongParts * kUpsNodes * sizeof(double2));
+  const size_t b_t1 = pad((size_t)chunk * kUpsNodes * n_stored_max * sizeof(double2));
+  const size_t b_cc = pad((size_t)chunk * kUpsLongParts * kUpsNodes * kUpsNodes * sizeof(double2));
   int rc;
-  if ((rc = ctx->ups.reserve(b_ups + b_abs + b_pu + b_nq + b_g + b_t1))) return rc;
+  if ((rc = get_ups_grid(ctx, uf, n_up, ws))) return rc;
+  if ((rc = ctx->ups.reserve(b_ups + b_abs + b_pu + b_nq + b_g + b_t1 + b_cc))) return rc;
   char* base = reinterpret_cast<char*>(ctx->ups.ptr);
   ws->n_up = n_up;
   ws->uf = (double)uf;
@@ -3957,6 +4201,7 @@ static int reserve_subpixel(mistitch_ctx* ctx, int n_pairs, int chunk, int abs_s
   ws->nq = reinterpret_cast<double2*>(base + b_ups + b_abs + b_pu);
   ws->gxy = reinterpret_cast<double2*>(base + b_ups + b_abs + b_pu + b_nq);
   ws->t1 = reinterpret_cast<double2*>(base + b_ups + b_abs + b_pu + b_nq + b_g);
+  ws->ccn = reinterpret_cast<double2*>(base + b_ups + b_abs + b_pu + b_nq + b_g + b_t1);
   ws->n_stored_max = n_stored_max;
   return MISTITCH_OK;
 }
@@ -4018,25 +4263,51 @@ static int launch_subpixel(mistitch_ctx* ctx, const UpsTables& tb, const RegWork
   // slabs per workgroup: two, so that two workgroups per CU overlap each other's staging (four measured
   // slower); one where LDS does not hold two
   const size_t slab_lds = (size_t)Sr * 2 * kSlab * sizeof(double);
-  int ns_ups = 2;
+#ifndef MS_UPS_NS
+#define MS_UPS_NS 2
+#endif
+  int ns_ups = MS_UPS_NS;
   while (ns_ups > 1 && ns_ups * slab_lds > 144 * 1024) ns_ups >>= 1;
   MS_REQUIRE(slab_lds <= kLdsMax, MISTITCH_ERR_UNSUPPORTED, "short side %d too long for the subpixel stage", S);
 #define MS_UPS_SHORT(NS)                                                                                             \
   do {                                                                                                               \
-    if ((rc = allow_lds(ctx, k_ups_short<T, NS>, NS * slab_lds))) return rc;                                         \
+    const size_t ups_lds = std::max(NS * slab_lds, (size_t)NS * 4096); /* the slabs, then the sums of half the waves */ \
+    if ((rc = allow_lds(ctx, k_ups_short<T, NS>, ups_lds))) return rc;                                               \
     MS_LAUNCH(ctx, "k_ups_short", (k_ups_short<T, NS>), dim3((tb.n_slabs + NS - 1) / NS, n), dim3(kThreads),         \
-              NS * slab_lds, ws.desc, status, pair0, S, L, want_transposed, Sr, pair_stride, tb.slabs, tb.n_slabs,   \
-              tb.pos2stored, tb.stored2kappa, ws.n_stored_max, rslabs, ws.ups, ws.n_up, ws.uf, ws.t1, ws.nq);        \
+              ups_lds, ws.desc, status, pair0, S, L, want_transposed, Sr, pair_stride, tb.slabs, tb.n_slabs,   \
+              tb.pos2stored, tb.stored2kappa, ws.n_stored_max, rslabs, ws.ups, ws.ups_node, ws.t1, ws.nq);           \
+  } while (0)
+  // Slabs per workgroup of the register-resident first stage: two workgroups fit a CU (128 registers per lane, 512
+  // lanes), and a launch whose workgroups all start together has no ragged last round: the pairs of a pass share
+  // the device's slots evenly (a pass of 128 pairs on 256 CUs: four workgroups per pair, 33 slabs each).
+#ifdef MS_UPS_GROUP
+  const int ups_group = MS_UPS_GROUP;
+#else
+  const int ups_wgs_per_pair = std::max(1, std::min(tb.n_slabs, 2 * ctx->n_cus / std::max(1, n)));
+  const int ups_group = std::min(kUpsGroupMax, std::max(1, (tb.n_slabs + ups_wgs_per_pair - 1) / ups_wgs_per_pair));
+#endif
+#define MS_UPS_SHORT_REG(QS)                                                                                         \
+  do {                                                                                                               \
+    const size_t reg_lds = slab_lds + 8 * 4 * 64 * sizeof(double) + kUpsGroupMax * (1 + 2 * kSlab) * sizeof(uint16_t); \
+    if ((rc = allow_lds(ctx, k_ups_short_reg<T, QS>, reg_lds))) return rc;                                           \
+    MS_LAUNCH(ctx, "k_ups_short", (k_ups_short_reg<T, QS>), dim3((tb.n_slabs + ups_group - 1) / ups_group, n),       \
+              dim3(kUpsShortThreads), reg_lds, ws.desc, status, pair0, S, L, want_transposed, Sr, pair_stride,       \
+              tb.slabs, tb.n_slabs, tb.pos2stored, tb.stored2kappa, ws.n_stored_max, rslabs, ws.ups, ws.ups_node,    \
+              ws.t1, ws.nq, ups_group);                                                                              \
   } while (0)
   if (tb.n_slabs > 0) {
-    if (ns_ups == 2) MS_UPS_SHORT(2);
+    // short sides up to 512 keep E in registers (32 or 64 steps per quarter of the kk range)
+    if (Sr <= 256) MS_UPS_SHORT_REG(32);
+    else if (Sr <= 512) MS_UPS_SHORT_REG(64);
+    else if (ns_ups == 2) MS_UPS_SHORT(2);
     else MS_UPS_SHORT(1);
   }
 #undef MS_UPS_SHORT
-  MS_LAUNCH(ctx, "k_ups_nyquist", k_ups_nyquist, dim3(n), dim3(kNyqParts * 256), 0, ws.desc, status, pair0, S, L,
-            want_transposed, tb.kappa, ws.n_stored_max, ws.nq, ws.ups, ws.n_up, ws.uf, ws.gxy);
-  MS_LAUNCH(ctx, "k_ups_long", k_ups_long, dim3(ws.n_row_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, S, L,
-            want_transposed, tb.kappa, ws.n_stored_max, ws.t1, ws.gxy, ws.ups, ws.n_up, ws.uf, ws.partial_ups,
+#undef MS_UPS_SHORT_REG
+  MS_LAUNCH(ctx, "k_ups_long", k_ups_long, dim3(kUpsLongParts, n), dim3(kUpsLongThreads), 0, ws.desc, status, pair0, S, L,
+            want_transposed, tb.kappa, ws.n_stored_max, ws.t1, ws.nq, ws.ups, ws.ups_node, ws.ccn, ws.gxy);
+  MS_LAUNCH(ctx, "k_ups_interp", k_ups_interp, dim3(ws.n_row_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, S, L,
+            want_transposed, ws.ccn, ws.gxy, ws.ups_node, ws.ups_p, ws.ups_pt, ws.ups, ws.n_up, ws.partial_ups,
             ws.n_row_blocks);
   return MISTITCH_OK;
 }

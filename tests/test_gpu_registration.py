@@ -229,6 +229,25 @@ def test_subpixel_shift_of_any_size(reg):
         assert np.abs(got - np.array([-dy, -dx])).max() < 0.1, (got, dy, dx)
 
 
+def test_subpixel_shift_equals_the_direct_sums_on_the_grid(reg):
+    """The upsampled correlation is evaluated at 32 x 32 Chebyshev nodes and interpolated to the grid (exact to
+    rounding for a function of its bandwidth), so the argmax on the 1 / upsample grid equals the one of the direct
+    matrix products in the NumPy restatement - not merely within 0.01 px.  Short sides up to 256 and up to 512 keep
+    the first-stage matrix in registers (two instantiations), longer ones take the rotor kernel.  Small strips with
+    an even long side that is not a power of two are the sensitive ones: their Nyquist column carries 1 / L of the
+    spectrum and counts as the negative frequency."""
+    from oracle import subpixel as osp
+    cases = [(64, 256, 0.37, -1.24, 100), (256, 2048, -1.63, 2.18, 100), (128, 512, 0.05, 0.49, 37),
+             (300, 600, 1.21, -2.4, 100), (384, 512, -0.71, 0.33, 100), (600, 700, 0.45, 1.9, 100),
+             (45, 300, -1.4, 0.85, 10), (2, 64, 0.0, 1.3, 100), (6, 40, 0.4, -0.6, 100), (8, 24, 0.4, -0.6, 100),
+             (33, 101, -0.3, 0.7, 100), (40, 8, 0.6, 0.2, 100), (12, 36, 0.4, -0.6, 64)]
+    for seed, (h, w, dy, dx, uf) in enumerate(cases):
+        a, b = _subpixel_pair(300 + seed, h, w, dy, dx)
+        want = osp.phase_cross_correlation(a, b, uf)
+        got = reg.phase_cross_correlation(a, b, uf)
+        assert np.abs(got - want).max() < 1e-9, (h, w, uf, got, want)
+
+
 def test_register_pairs_with_subpixel_candidate_any_size(reg):
     """Subpixel candidate on a grid whose strips are not powers of two (300 x 420 tiles, edge 45)."""
     from oracle import subpixel as osp

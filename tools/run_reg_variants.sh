@@ -1,8 +1,6 @@
 #!/bin/bash
-# time the shipped library and every variant named on the command line with tools/reg_probe.py
-# usage: run_reg_variants.sh <edge> <f64|f32> <variant>...
-edge=$1; fft=$2; shift 2
-timeout -k 10 120 python tools/reg_probe.py $edge $fft || exit 1
-for v in "$@"; do
-  MISTITCH_LIB=$PWD/tools/variants/$v.so timeout -k 10 120 python tools/reg_probe.py $edge $fft || exit 1
+# time every library variant under tools/variants with the registration probe; arguments are passed on to it
+for f in tools/variants/*.so; do
+  echo "== $f"
+  MISTITCH_LIB=$PWD/$f timeout -k 10 200 python tools/reg_probe.py "$@" 2>&1 | grep -v amdgpu.ids | tail -1 || exit 1
 done
