@@ -198,9 +198,12 @@ int mistitch_refine_pairs(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles,
  * coarse shift is the largest |PCM| value, refined on a ceil(1.5 u) square grid
  * of spacing 1/u.  Replaces skimage.registration.phase_cross_correlation(a, b,
  * upsample_factor=u, normalization='phase') as the reference calls it
- * (_translation_computation.py:1233-1272).  Any strip sides up to 4096 (strips of
- * other than power-of-two sides are transformed in float64 whatever the flags say);
- * 2 <= u <= 106.
+ * (_translation_computation.py:1233-1272).  The grid values are not summed one by one:
+ * the correlation is evaluated at 32 x 32 Chebyshev nodes of the grid's span and
+ * interpolated to the grid, which for a function of its bandwidth is exact to rounding
+ * error (the argmax on the grid is that of the direct sums).  Any strip sides up to 4096
+ * (strips of other than power-of-two sides are transformed in float64 whatever the flags
+ * say); 2 <= u <= 106.
  *   out_shift  [2] float64: (dy, dx)                                               */
 int mistitch_subpixel_shift(mistitch_ctx* ctx, const uint16_t* strip1, int64_t pitch1,
                             const uint16_t* strip2, int64_t pitch2, int h, int w, unsigned flags,
