@@ -738,6 +738,18 @@ __global__ __launch_bounds__(N / 8) void k_fft_long_fwd_reg(const PairDesc* desc
   for (int i = 0; i < 8; ++i) to[(int64_t)(8 * i) * sp] = from[72 * i];
 }
 
+// The spectra of two strips of INTEGER pixels are integers at the frequencies that are their own negatives (0 or half
+// the length along both axes): |value| <= 65535 S L < 2^53, and a float64 transform is off by far less than 0.5 there,
+// so rounding recovers them exactly - as numpy's transforms deliver them for lengths of radix 2, 3 and 4.  It matters
+// when such a sum is exactly zero (an alternating sum of pixels that happens to cancel): the normalised cross-power
+// value is then 0, where the rounding residue of a transform would be normalised to magnitude 1 with an arbitrary sign
+// (1 / (S L) of every PCM value).  Not applied to windowed (non-integer) strips.
+__device__ __forceinline__ void exact_real_bin(double& a, double& b) {
+  a = rint(a);
+  b = rint(b);
+}
+__device__ __forceinline__ void exact_real_bin(float&, float&) {}  // complex64: the sums exceed 24 bits
+
 template <typename T>
 __device__ __forceinline__ T cabs_safe(T x, T y);
 template <>
@@ -770,7 +782,7 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
                                                       int want_transposed, FftPlanDev planS, FftPlanDev planL,
                                                       const CpsUnit* __restrict__ units, int rs, const cx<T>* slabs,
                                                       cx<T>* spectrum, T eps, cx<T>* keep_r,
-                                                      const uint16_t* __restrict__ pos2stored, int n_stored) {
+                                                      const uint16_t* __restrict__ pos2stored, int n_stored, int exact) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cx<T>* buf = reinterpret_cast<cx<T>*>(smem_raw);
   const int p = pair0 + blockIdx.y;
@@ -877,8 +889,9 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
     const cx<T> zm = buf[q2 * rs + pc];
     // z = A + iB with A, B the spectra of the two real strips:
     // A = (z + conj(zm)) / 2,  B = (z - conj(zm)) / (2i)
-    const T ax = (T)0.5 * (z.x + zm.x), ay = (T)0.5 * (z.y - zm.y);
-    const T bx = (T)0.5 * (z.y + zm.y), by = (T)-0.5 * (z.x - zm.x);
+    T ax = (T)0.5 * (z.x + zm.x), ay = (T)0.5 * (z.y - zm.y);
+    T bx = (T)0.5 * (z.y + zm.y), by = (T)-0.5 * (z.x - zm.x);
+    if (exact && (q2 * rs + pc) == (q * rs + c)) exact_real_bin(ax, bx);  // its own partner: A = Re z, B = Im z
     T fx = ax * bx + ay * by;  // A * conj(B)
     T fy = ay * bx - ax * by;
     const T inv = (T)1 / (cabs_safe<T>(fx, fy) + eps);
@@ -953,7 +966,7 @@ __global__ __launch_bounds__(2 * NC * S / 8, NC == 8 ? 4 : 4) void k_fft_short_c
     const PairDesc* desc, const int8_t* status, int pair0, int L, int want_transposed, const double2* __restrict__ roots,
     const uint16_t* __restrict__ mpos_s, const uint16_t* __restrict__ pos2freq_s, const uint16_t* __restrict__ mpos_l,
     const CpsUnit* __restrict__ units, int n_units, const double2* slabs, double2* spectrum, double eps, double2* keep_r,
-    const uint16_t* __restrict__ pos2stored, int n_stored) {
+    const uint16_t* __restrict__ pos2stored, int n_stored, int exact) {
   constexpr int Q = S / 8;            // lanes per column
   constexpr int R0 = S / 64;          // radix of the first pass
   constexpr int NB = 8 / R0;          // its butterflies per lane
@@ -1036,8 +1049,9 @@ __global__ __launch_bounds__(2 * NC * S / 8, NC == 8 ? 4 : 4) void k_fft_short_c
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const double2 z = v[h + m];
-      const double ax = 0.5 * (z.x + zm[m].x), ay = 0.5 * (z.y - zm[m].y);
-      const double bx = 0.5 * (z.y + zm[m].y), by = -0.5 * (z.x - zm[m].x);
+      double ax = 0.5 * (z.x + zm[m].x), ay = 0.5 * (z.y - zm[m].y);
+      double bx = 0.5 * (z.y + zm[m].y), by = -0.5 * (z.x - zm[m].x);
+      if (exact && single && mp == a_base + c && (int)mrow[h + m] == 8 * q + h + m) exact_real_bin(ax, bx);  // its own partner
       double fx = ax * bx + ay * by;  // A * conj(B)
       double fy = ay * bx - ax * by;
       const double inv = 1.0 / (cabs_safe<double>(fx, fy) + eps);
@@ -1711,7 +1725,8 @@ __global__ __launch_bounds__(kGenShortThreads) void k_fft_short_cps_gen(const Pa
                                                                 FftPlanDev planL, const CpsUnit* __restrict__ units,
                                                                 int lines, const double2* slabs, double2* spectrum,
                                                                 double eps, double2* keep_r,
-                                                                const uint16_t* __restrict__ pos2stored, int n_stored) {
+                                                                const uint16_t* __restrict__ pos2stored, int n_stored,
+                                                                int exact) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double2* buf = reinterpret_cast<double2*>(smem_raw);
   const int p = pair0 + blockIdx.y;
@@ -1748,8 +1763,9 @@ __global__ __launch_bounds__(kGenShortThreads) void k_fft_short_cps_gen(const Pa
     if (partner_in_a && (q2 * 64 + pc) < (q * 64 + c)) continue;  // the partner cell's owner writes both
     const double2 z = buf[addr(c, q)];
     const double2 zm = buf[addr(pc, q2)];
-    const double ax = 0.5 * (z.x + zm.x), ay = 0.5 * (z.y - zm.y);
-    const double bx = 0.5 * (z.y + zm.y), by = -0.5 * (z.x - zm.x);
+    double ax = 0.5 * (z.x + zm.x), ay = 0.5 * (z.y - zm.y);
+    double bx = 0.5 * (z.y + zm.y), by = -0.5 * (z.x - zm.x);
+    if (exact && (q2 * 64 + pc) == (q * 64 + c)) exact_real_bin(ax, bx);  // its own partner
     double fx = ax * bx + ay * by;  // A * conj(B)
     double fy = ay * bx - ax * by;
     const double inv = 1.0 / (cabs_safe<double>(fx, fy) + eps);
@@ -1844,7 +1860,7 @@ __global__ __launch_bounds__(kThreads) void k_gen_cols(const PairDesc* desc, con
 // grid (blocks, pairs_in_pass).
 __global__ __launch_bounds__(kThreads) void k_gen_cps(const PairDesc* desc, const int8_t* status, int pair0, int S,
                                                       int L, int want_transposed, const double2* __restrict__ Zf,
-                                                      double2* __restrict__ R, double eps) {
+                                                      double2* __restrict__ R, double eps, int exact) {
   const int p = pair0 + blockIdx.y;
   if (status[p] != MISTITCH_PAIR_OK) return;
   {
@@ -1857,8 +1873,9 @@ __global__ __launch_bounds__(kThreads) void k_gen_cps(const PairDesc* desc, cons
     const int q = e / L, c = e - q * L;
     const double2 z = zf[e];
     const double2 zm = zf[(int64_t)((S - q) % S) * L + (L - c) % L];
-    const double ax = 0.5 * (z.x + zm.x), ay = 0.5 * (z.y - zm.y);
-    const double bx = 0.5 * (z.y + zm.y), by = -0.5 * (z.x - zm.x);
+    double ax = 0.5 * (z.x + zm.x), ay = 0.5 * (z.y - zm.y);
+    double bx = 0.5 * (z.y + zm.y), by = -0.5 * (z.x - zm.x);
+    if (exact && (S - q) % S == q && (L - c) % L == c) exact_real_bin(ax, bx);  // its own partner
     double fx = ax * bx + ay * by;  // A * conj(B)
     double fy = ay * bx - ax * by;
     const double inv = 1.0 / (cabs_safe<double>(fx, fy) + eps);
@@ -4407,6 +4424,7 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
                        (const double*)nullptr, (const double*)nullptr);
   }
   const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
+  const int exact_bins = ws.window ? 0 : 1;  // integer strips: the self-conjugate frequencies are rounded to their exact values
   bool column_pass_done = false;
   if constexpr (std::is_same<T, double>::value) {
     if (cfg.mixed_short) {
@@ -4414,13 +4432,13 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
       if ((rc = allow_lds(ctx, k_fft_short_cps<double, kNT, 8, true>, cfg.lds_cps))) return rc;
       MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<double, kNT, 8, true>), dim3(cfg.n_units, n), dim3(kNT), cfg.lds_cps,
                 ws.desc, status, pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec,
-                eps, ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
+                eps, ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored, exact_bins);
       column_pass_done = true;
     } else if (cfg.gen_short) {
       if ((rc = allow_lds(ctx, k_fft_short_cps_gen, cfg.lds_cps))) return rc;
       MS_LAUNCH(ctx, "k_fft_short_cps", k_fft_short_cps_gen, dim3(cfg.n_units, n), dim3(kGenShortThreads), cfg.lds_cps, ws.desc, status,
                 pair0, cfg.S, cfg.L, want_transposed, cfg.gpS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps,
-                ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
+                ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored, exact_bins);
       column_pass_done = true;
     }
   }
@@ -4436,19 +4454,19 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
     if (!getenv("MISTITCH_CPS_HALF_UNITS")) {  /* whole units by default: halves measured 2 % slower */                                                                          \
       MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps_reg<SS, 8>), dim3(cfg.n_units, n), dim3(2 * SS), lds8, ws.desc, \
                 status, pair0, cfg.L, want_transposed, roots, cfg.planS.mpos, cfg.planS.pos2freq, cfg.planL.mpos,       \
-                cfg.units, cfg.n_units, slabs, spec, (double)eps, keep, cfg.pos2stored, cfg.n_stored);                  \
+                cfg.units, cfg.n_units, slabs, spec, (double)eps, keep, cfg.pos2stored, cfg.n_stored, exact_bins);                  \
     } else {                                                                                                           \
       if ((rc = allow_lds(ctx, k_fft_short_cps_reg<SS, 4>, lds4))) return rc;                                          \
       if (cfg.n_paired > 0)                                                                                            \
         MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps_reg<SS, 4>), dim3(16 * ((cfg.n_paired + 7) / 8), n), dim3(SS), \
                   lds4, ws.desc, status, pair0, cfg.L, want_transposed, roots, cfg.planS.mpos, cfg.planS.pos2freq,     \
                   cfg.planL.mpos, cfg.units_paired, cfg.n_paired, slabs, spec, (double)eps, keep, cfg.pos2stored,      \
-                  cfg.n_stored);                                                                                       \
+                  cfg.n_stored, exact_bins);                                                                           \
       if (cfg.n_single > 0)                                                                                            \
         MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps_reg<SS, 8>), dim3(cfg.n_single, n), dim3(2 * SS), lds8,     \
                   ws.desc, status, pair0, cfg.L, want_transposed, roots, cfg.planS.mpos, cfg.planS.pos2freq,           \
                   cfg.planL.mpos, cfg.units_single, cfg.n_single, slabs, spec, (double)eps, keep, cfg.pos2stored,      \
-                  cfg.n_stored);                                                                                       \
+                  cfg.n_stored, exact_bins);                                                                           \
     }                                                                                                                  \
   } while (0)
       if (cfg.S == 128) MS_CPS_REG(128);
@@ -4463,7 +4481,7 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
     if ((rc = allow_lds(ctx, k_fft_short_cps<T, kNT, kSR>, cfg.lds_cps))) return rc;
     MS_LAUNCH(ctx, "k_fft_short_cps", (k_fft_short_cps<T, kNT, kSR>), dim3(cfg.n_units, n), dim3(kNT), cfg.lds_cps, ws.desc,
               status, pair0, cfg.S, cfg.L, want_transposed, cfg.planS, cfg.planL, cfg.units, 2 * cfg.C, slabs, spec, eps,
-              ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored);
+              ws.n_up ? slabs : (cx<T>*)nullptr, cfg.pos2stored, cfg.n_stored, exact_bins);
   }
   // Where the last radix pass ranks its values (two peaks, no PCM plane), a workgroup takes several blocks of lines
   // in turn and reduces once - as long as the launch still fills the chip a few times over.
@@ -4551,7 +4569,7 @@ static int launch_fft_general(mistitch_ctx* ctx, const GenShape& g, const RegWor
             want_transposed, g.ps, g.C, 0, Zf);
   const int cps_blocks = std::max(1, std::min(1024, (g.S * g.L + kThreads - 1) / kThreads));
   MS_LAUNCH(ctx, "k_gen_cps", k_gen_cps, dim3(cps_blocks, n), dim3(kThreads), 0, ws.desc, status, pair0, g.S, g.L,
-            want_transposed, Zf, R, eps);
+            want_transposed, Zf, R, eps, ws.window ? 0 : 1);
   const int64_t keep_stride = slab_pair_elems(g.Sr, g.n_cols8);
   if (ws.n_up) {
     // the forward spectra are no longer needed: their buffer takes the copy of R the subpixel stage reads

@@ -15,7 +15,7 @@ spec.loader.exec_module(fz)
 CASES = {"registration": 150, "fusion": 150, "subpixel": 80, "refine": 80, "fusion_wide": 60, "registration_big": 12,
          "apis": 150, "pipeline": 60, "registration_tiny": 400, "fusion_tiny": 300,
          "featureless": 300, "registration_wild": 200, "fusion_ff_extreme": 300, "mixed_radix": 100, "peaks10": 100,
-         "window": 100, "consensus": 150, "fusion_chunked": 200, "u8": 150, "bitshuffle": 150}
+         "window": 100, "consensus": 150, "fusion_chunked": 200, "u8": 150, "bitshuffle": 150, "subpixel_raw": 120}
 
 
 @pytest.mark.parametrize("kind", sorted(CASES))
@@ -28,6 +28,7 @@ def test_random_inputs_agree_with_the_oracle(kind):
     run = {"registration": lambda: fz.fuzz_registration(rng, reg, oreg, synth),
            "fusion": lambda: fz.fuzz_fusion(rng, fu, ofu, synth),
            "subpixel": lambda: fz.fuzz_subpixel(rng, reg, osp, synth),
+           "subpixel_raw": lambda: fz.fuzz_subpixel_raw(rng, reg, osp, synth),
            "refine": lambda: fz.fuzz_refine(rng, reg, oref, synth),
            "fusion_wide": lambda: fz.fuzz_fusion_wide(rng, fu, ofu, synth),
            "registration_big": lambda: fz.fuzz_registration_big(rng, reg, oreg, synth),

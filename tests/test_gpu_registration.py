@@ -72,6 +72,41 @@ def test_pcm_of_any_size(reg, shape):
             assert (rows[i], cols[i]) == (er[i], ec[i])
 
 
+@pytest.mark.parametrize("shape", [(8, 64), (256, 2048), (4, 24), (12, 64), (34, 64), (6, 40), (195, 256)])
+@pytest.mark.parametrize("which", ["both_nyquist", "long_nyquist", "short_nyquist"])
+def test_pcm_with_an_exactly_cancelling_self_conjugate_frequency(reg, shape, which):
+    """A strip whose alternating pixel sum is exactly zero has an exactly zero spectrum value at that self-conjugate
+    frequency: NumPy's transform delivers the zero and the normalised cross-power value there is 0; a transform that
+    leaves a rounding residue instead would normalise it to magnitude 1 (1 / (h w) of every PCM value, enough to
+    reorder close peaks).  Shapes where NumPy's own sum is not exact (its radix-3 and larger passes) are skipped."""
+    h, w = shape
+    rng = np.random.default_rng(h * 1000 + w)
+    a = rng.integers(1000, 60000, size=(h, w)).astype(np.int64)
+    b = np.roll(a, (1, -2), axis=(0, 1)) + rng.integers(0, 50, size=(h, w))
+    sy = (-1) ** np.arange(h)[:, None] if which != "long_nyquist" else np.ones((h, 1), dtype=np.int64)
+    sx = (-1) ** np.arange(w)[None, :] if which != "short_nyquist" else np.ones((1, w), dtype=np.int64)
+    sign = sy * sx
+    # move the signed sum of `a` to zero, a few pixels at a time, staying inside uint16
+    residue = int((sign * a).sum())
+    flat, sflat = a.reshape(-1), np.broadcast_to(sign, a.shape).reshape(-1)
+    for i in range(flat.size):
+        if residue == 0:
+            break
+        want_down = (residue > 0) == (sflat[i] > 0)  # lowering a +pixel or raising a -pixel lowers the sum
+        room = int(flat[i]) if want_down else 65535 - int(flat[i])
+        step = min(abs(residue), room, 20000)
+        flat[i] += -step if want_down else step
+        residue += -step if residue > 0 else step
+    assert int((sign * a).sum()) == 0 and a.min() >= 0 and a.max() <= 65535
+    ky, kx = (h // 2 if which != "long_nyquist" else 0), (w // 2 if which != "short_nyquist" else 0)
+    if (h % 2 and ky) or (w % 2 and kx) or np.fft.fft2(a.astype(np.float64))[ky, kx] != 0:
+        pytest.skip("NumPy's own value at this frequency is a rounding residue for this length: nothing to agree with")
+    a16, b16 = a.astype(np.uint16), b.astype(np.uint16)
+    ref = oreg.pcm(a16, b16)
+    got = reg.pcm(a16, b16)
+    assert np.abs(got - ref).max() < 1e-10, (shape, which, np.abs(got - ref).max(), 1.0 / (h * w))
+
+
 def test_matches_oracle_on_fresh_seeds(reg):
     for seed, (rows, cols, th, tw, ew) in enumerate([(3, 4, 256, 256, 32), (2, 5, 128, 512, 64), (4, 2, 512, 128, 64)]):
         g = synth.make_grid(100 + seed, rows, cols, th, tw, overlap=0.15, jitter=4)

@@ -97,6 +97,42 @@ def fuzz_subpixel(rng, reg, osp, synth):
         (out, st, exp, exp_st)
 
 
+def fuzz_subpixel_raw(rng, reg, osp, synth):
+    """The raw upsampled-DFT shift of one strip pair (a smooth scene resampled at a fractional offset, so the
+    correlation has one clear peak) must equal the restatement's on the 1 / upsample grid: the node evaluation is
+    exact to rounding, and near-ties between grid neighbours do not occur away from noise plateaus."""
+    r = rng.random()
+    if r < 0.35:
+        h, w = int(2 ** rng.integers(3, 9)), int(2 ** rng.integers(5, 11))
+    elif r < 0.6:
+        h, w = int(rng.integers(6, 48)), int(rng.integers(24, 160))
+    else:
+        h, w = int(rng.integers(30, 300)), int(rng.integers(40, 700))
+    if rng.random() < 0.3:
+        h, w = w, h
+    dy, dx = float(rng.uniform(-3, 3)), float(rng.uniform(-6, 6))
+    uf = int(rng.choice([100, 100, 100, 10, 37, 64, 2]))
+    big = rng.random((h + 32, w + 32))
+    fy, fx = np.fft.fftfreq(h + 32)[:, None], np.fft.fftfreq(w + 32)[None, :]
+    low = np.fft.ifft2(np.fft.fft2(big) * np.exp(-(fy ** 2 + fx ** 2) * 4.0)).real
+    moved = np.fft.ifft2(np.fft.fft2(low) * np.exp(-2j * np.pi * (fy * dy + fx * dx))).real
+    to_u16 = lambda img: np.clip(1000 + 50000 * (img - low.min()) / (low.max() - low.min()), 0, 65535).astype(np.uint16)
+    a = np.ascontiguousarray(to_u16(low)[16:16 + h, 16:16 + w])
+    b = np.ascontiguousarray(to_u16(moved)[16:16 + h, 16:16 + w])
+    desc = dict(kind="subpixel_raw", strip=(h, w), shift=(dy, dx), uf=uf)
+    try:
+        got = np.asarray(reg.phase_cross_correlation(a, b, uf))
+    except Exception as exc:  # strips too small for the stage are refused, not mis-registered
+        if "too small" in str(exc):
+            STATS["subpixel_raw_refused"] = STATS.get("subpixel_raw_refused", 0) + 1
+            return True, desc, None
+        raise
+    want = osp.phase_cross_correlation(a, b, uf)
+    good = bool(np.abs(got - want).max() < 1e-9)
+    z = np.zeros(1)
+    return good, desc, (got[None, :], z, want[None, :], z)
+
+
 def fuzz_refine(rng, reg, oref, synth):
     rows, cols = int(rng.integers(1, 3)), int(rng.integers(2, 4))
     th, tw = int(rng.integers(40, 200)), int(rng.integers(40, 200))
@@ -567,6 +603,7 @@ def main():
     runners = {"registration": lambda: fuzz_registration(rng, reg, oreg, synth),
                "fusion": lambda: fuzz_fusion(rng, fu, ofu, synth),
                "subpixel": lambda: fuzz_subpixel(rng, reg, osp, synth),
+               "subpixel_raw": lambda: fuzz_subpixel_raw(rng, reg, osp, synth),
                "refine": lambda: fuzz_refine(rng, reg, oref, synth),
                "fusion_wide": lambda: fuzz_fusion_wide(rng, fu, ofu, synth),
                "registration_big": lambda: fuzz_registration_big(rng, reg, oreg, synth),
@@ -593,7 +630,7 @@ def main():
         counts[kind] += 1
         if not good:
             print("DISAGREEMENT", desc, flush=True)
-            if kind in ("registration", "subpixel", "refine", "registration_big", "registration_tiny", "featureless", "registration_wild", "mixed_radix", "peaks10", "window", "consensus") or desc.get("api") in ("ncc", "pcm_topk"):
+            if kind in ("registration", "subpixel", "subpixel_raw", "refine", "registration_big", "registration_tiny", "featureless", "registration_wild", "mixed_radix", "peaks10", "window", "consensus") or desc.get("api") in ("ncc", "pcm_topk"):
                 out, st, exp, exp_st = data
                 print(np.concatenate([out, st[:, None], exp, exp_st[:, None]], axis=1))
             else:
