@@ -4424,7 +4424,8 @@ static int launch_fft(mistitch_ctx* ctx, const ShapeCfg& cfg, const RegWorkspace
                        (const double*)nullptr, (const double*)nullptr);
   }
   const T eps = (T)(std::numeric_limits<double>::epsilon() * 100.0);
-  const int exact_bins = ws.window ? 0 : 1;  // integer strips: the self-conjugate frequencies are rounded to their exact values
+  // integer strips: the self-conjugate frequencies are rounded to their exact values (MISTITCH_NO_EXACT_BINS: a diagnostic switch)
+  const int exact_bins = (ws.window || getenv("MISTITCH_NO_EXACT_BINS")) ? 0 : 1;
   bool column_pass_done = false;
   if constexpr (std::is_same<T, double>::value) {
     if (cfg.mixed_short) {
