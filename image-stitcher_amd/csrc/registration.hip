@@ -1033,6 +1033,19 @@ __global__ __launch_bounds__(2 * NC * S / 8, NC == 8 ? 4 : 4) void k_fft_short_c
 #pragma unroll
   for (int m = 0; m < 8; ++m) v[m] = at_c[m * NC];
   RegFft<512>::butterfly<8, false>(v, mk<double>(1.0, 0.0), false);
+  if (exact && single && half == 0 && mp == a_base + c) {
+    // a cell that is its own partner holds A = Re z, B = Im z, integers (see exact_real_bin): rounded here, before
+    // the copy that the partner read below fetches, and outside the cross-power loop, which has no register to spare
+    const unsigned own = 8u * (unsigned)q;
+    if ((mrow4.x & 0xffffu) == own) exact_real_bin(v[0].x, v[0].y);
+    if ((mrow4.x >> 16) == own + 1) exact_real_bin(v[1].x, v[1].y);
+    if ((mrow4.y & 0xffffu) == own + 2) exact_real_bin(v[2].x, v[2].y);
+    if ((mrow4.y >> 16) == own + 3) exact_real_bin(v[3].x, v[3].y);
+    if ((mrow4.z & 0xffffu) == own + 4) exact_real_bin(v[4].x, v[4].y);
+    if ((mrow4.z >> 16) == own + 5) exact_real_bin(v[5].x, v[5].y);
+    if ((mrow4.w & 0xffffu) == own + 6) exact_real_bin(v[6].x, v[6].y);
+    if ((mrow4.w >> 16) == own + 7) exact_real_bin(v[7].x, v[7].y);
+  }
 #pragma unroll
   for (int m = 0; m < 8; ++m) at_c[m * NC] = v[m];
   lds_barrier();
@@ -1049,9 +1062,8 @@ __global__ __launch_bounds__(2 * NC * S / 8, NC == 8 ? 4 : 4) void k_fft_short_c
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const double2 z = v[h + m];
-      double ax = 0.5 * (z.x + zm[m].x), ay = 0.5 * (z.y - zm[m].y);
-      double bx = 0.5 * (z.y + zm[m].y), by = -0.5 * (z.x - zm[m].x);
-      if (exact && single && mp == a_base + c && (int)mrow[h + m] == 8 * q + h + m) exact_real_bin(ax, bx);  // its own partner
+      const double ax = 0.5 * (z.x + zm[m].x), ay = 0.5 * (z.y - zm[m].y);
+      const double bx = 0.5 * (z.y + zm[m].y), by = -0.5 * (z.x - zm[m].x);
       double fx = ax * bx + ay * by;  // A * conj(B)
       double fy = ay * bx - ax * by;
       const double inv = 1.0 / (cabs_safe<double>(fx, fy) + eps);
