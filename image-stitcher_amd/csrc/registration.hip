@@ -1402,7 +1402,12 @@ __global__ __launch_bounds__(N / 8, 4) void k_fft_long_inv_reg(const PairDesc* d
   const double2* Z = spectrum + (int64_t)blockIdx.y * S * Lp;
   // lines s0, s0 + 1 into LDS as g1 + i g2; false (for every lane alike) when the pair is not this launch's
   auto load_lines = [&]() -> bool {
-    constexpr int U = 4;
+    // the stored half is N / 2 + 9 values: five per lane cover it in ONE round of loads (four would leave nine values
+    // to a second round, a second trip to memory in front of every transform)
+#ifndef MS_INV_LOADS
+#define MS_INV_LOADS 5
+#endif
+    constexpr int U = MS_INV_LOADS;
     const double2* z1 = Z + (int64_t)min(s0, S - 1) * Lp;      // lines past the last one read it and count as zero
     const double2* z2 = Z + (int64_t)min(s0 + 1, S - 1) * Lp;
     for (int e0 = tid; e0 < n_stored; e0 += NT * U) {
