@@ -27,7 +27,16 @@ constexpr int kGxPlain = MS_FUSE_GX_PLAIN;  // groups per lane and row without f
 constexpr int kGxFlat = MS_FUSE_GX_FF;      // with flatfield: fewer, the flatfield values take registers too
 constexpr int kBH = MS_FUSE_BH;             // block height in pixels
 constexpr int kMaxCand = 32;  // tiles remembered per block before the slow path
-static_assert(kBH <= 32 && kMaxCand == 32, "queue entries hold 5-bit rows and candidate indices");
+// Waves of a workgroup side by side along a row (1: each of the four waves takes its own rows of a 512 GX pixel wide
+// block; 4: the four waves take four neighbouring 512 GX pixel pieces of the SAME row, so that the flatfield row they
+// all read - neighbouring tiles of a grid row use the same one - is fetched into the CU's L1 once).  The queue entries
+// hold 13 bits of (group in the block row, row in the block): four waves across need blocks of 8 rows.
+#ifndef MS_FUSE_WX
+#define MS_FUSE_WX 1
+#endif
+constexpr int kWX = MS_FUSE_WX, kWY = (kFuseThreads / 64) / kWX;
+static_assert(kWX == 1 || kWX == 2 || kWX == 4, "waves across");
+static_assert(kBH * kWX <= 32 && kMaxCand == 32, "queue entries hold 13 bits of group and row, and 5-bit candidate indices");
 
 #ifndef MS_FDIV
 #define MS_FDIV(a, b) __fdiv_rn((a), (b))
@@ -543,8 +552,11 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
                                            uint16_t* __restrict__ mosaic, int Hm, int Wm, int row0, int row1, int gx,
                                            int gy, int n_planes, int64_t idle_off, int64_t idle_foff, const ChunkGeom cg,
                                            unsigned vmax) {
-  constexpr int kQueue = kBH * 64 * GX;
+  constexpr int kQueue = kBH * 64 * GX * kWX;
+  constexpr int kGroupBits = (64 * GX * kWX <= 256) ? 8 : (64 * GX * kWX <= 512 ? 9 : 10);  // group in the block row, then the row
+  static_assert(64 * GX * kWX <= 1024 && kBH <= (1 << (13 - kGroupBits)), "13 bits of group and row");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wx = wave % kWX, wy = wave / kWX;
   if (tid == 0) queue_len[0] = queue_len[1] = 0;
   // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  All
   // blocks of one block-row read the same flatfield rows (the tiles of a grid row
@@ -578,7 +590,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
   constexpr bool chunked = CH;  // (cg.on())
   uint16_t* mplane = mosaic + (chunked ? (int64_t)plane * cg.plane_elems() : (int64_t)plane * Hm * Wm);
   const int Wp = chunked ? cg.Wp() : Wm;  // columns that are written
-  const int w_idx = bx * (64 * GX) + lane;  // first aligned group of this lane within a row
+  const int w_idx = (bx * kWX + wx) * (64 * GX) + lane;  // first aligned group of this lane within a row
   int col_off[GX];  // chunk order: where the lane's groups lie inside a chunk row (they start at multiples of 8)
 #pragma unroll
   for (int r = 0; r < GX; ++r) col_off[r] = chunked ? cg.col_off(min(8 * w_idx + 512 * r, Wp - 8)) : 0;
@@ -596,7 +608,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
   // order 0, 8, 16, 24, 4, 12, 20, 28 (+ its number): consecutive rows share (a), and away from the tiles' first
   // and last rows (b) and (c) too, so that the classification of the previous row stands and only addresses,
   // loads and stores remain (vector instructions issue on 59 % of this kernel's cycles: they, not memory, set its pace).
-  constexpr int kWaves = kFuseThreads / 64;
+  constexpr int kWaves = kWY;  // waves that share a block's rows
   constexpr int kRowsPerWave = (kBH + kWaves - 1) / kWaves;
   unsigned kinds = 0;        // two bits per group
   unsigned csel = 0;         // 5 bits per group: the list entry a plain copy reads
@@ -609,7 +621,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
   for (int it = 0; it < kRowsPerWave; ++it) {
     const int half = (kRowsPerWave + 1) / 2;
     const int kk = it < half ? 2 * it : 2 * (it - half) + 1;  // even steps first, then the odd ones
-    const int y = y0 + wave + kk * kWaves;
+    const int y = y0 + wy + kk * kWaves;
     if (y >= y1) continue;  // wave-uniform
     uint16_t* rowp = mplane + (chunked ? cg.row_base(y) : (int64_t)y * Wm);
     const int a = chunked ? 0 : (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
@@ -683,7 +695,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
                              (MODE == MISTITCH_FUSE_FEATHER ? (full[r] && cnt[r] >= 2) : cnt[r] >= 1);
         const unsigned packed = cnt[r] <= 2 ? (i5 & 0x3ffu)
                                             : ((i5 & 15u) | ((i5 >> 1) & 0xf0u) | ((i5 >> 2) & 0xf00u) | ((i5 >> 3) & 0xf000u));
-        qinfo[r] = (unsigned)(lane + 64 * r) | (batched ? ((unsigned)(cnt[r] - 1) << 13) | (packed << 15) : 0u);
+        qinfo[r] = (unsigned)(wx * 64 * GX + lane + 64 * r) | (batched ? ((unsigned)(cnt[r] - 1) << 13) | (packed << 15) : 0u);
         qbatched |= (batched ? 1u : 0u) << r;
       }
     }
@@ -735,7 +747,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
       } else if (k == 2) {
         // queued for the whole workgroup: these groups cluster in the overlap bands, and
         // handled in place they would stall every wave that owns a few
-        const unsigned e = qinfo[r] | ((unsigned)(y - y0) << 8);
+        const unsigned e = qinfo[r] | ((unsigned)(y - y0) << kGroupBits);
         if ((qbatched >> r) & 1u)
           queue[atomicAdd(&queue_len[0], 1u)] = e;
         else
@@ -748,10 +760,10 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
     const unsigned n_blend = queue_len[0];
     for (unsigned i = tid; i < n_blend; i += kFuseThreads) {
       const unsigned e = queue[i];
-      const int y = y0 + (int)((e >> 8) & 31u);
+      const int y = y0 + (int)((e >> kGroupBits) & ((1u << (13 - kGroupBits)) - 1u));
       uint16_t* rowp = mplane + (chunked ? cg.row_base(y) : (int64_t)y * Wm);
       const int a = chunked ? 0 : (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
-      const int x = 8 * (bx * (64 * GX) + (int)(e & 0xffu)) - a;
+      const int x = 8 * (bx * (64 * GX * kWX) + (int)(e & ((1u << kGroupBits) - 1u))) - a;
       const int cnt = (int)((e >> 13) & 3u) + 1;
       const unsigned f = e >> 15;
       int ci[4];  // placement order; absent sources repeat the first
@@ -771,10 +783,10 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
   const unsigned n_generic = queue_len[1];
   for (unsigned i = tid; i < n_generic; i += kFuseThreads) {
     const unsigned e = queue[kQueue - 1 - i];
-    const int y = y0 + (int)((e >> 8) & 31u);
+    const int y = y0 + (int)((e >> kGroupBits) & ((1u << (13 - kGroupBits)) - 1u));
     uint16_t* rowp = mplane + (chunked ? cg.row_base(y) : (int64_t)y * Wm);
     const int a = chunked ? 0 : (int)((reinterpret_cast<uintptr_t>(rowp) >> 1) & 7);
-    const int x = 8 * (bx * (64 * GX) + (int)(e & 0xffu)) - a;
+    const int x = 8 * (bx * (64 * GX * kWX) + (int)(e & ((1u << kGroupBits) - 1u))) - a;
     const unsigned vm = (((1u << min(8, Wm - x)) - 1u) & ~((1u << max(0, -x)) - 1u)) & 0xffu;
     uint16_t px[8];
     resolve_window<MODE, FF>(y, x, vm, list, ncand, overflow, plane, tiles, H, W, tile_pitch, tile_yx, tile_plane,
@@ -799,7 +811,7 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
                                                        int row1, int gx, int gy, int n_planes, int64_t idle_off,
                                                        int64_t idle_foff, const ChunkGeom cg, unsigned vmax) {
   __shared__ TileRef list[kMaxCand];
-  __shared__ unsigned queue[kBH * 64 * GX];
+  __shared__ unsigned queue[kBH * 64 * GX * kWX];
   __shared__ unsigned queue_len[3];  // blend entries, pixel-by-pixel entries, candidates with a flatfield plane
   if constexpr (FF == MISTITCH_FF_F32) {
     if (*ff_safe) {
@@ -1079,7 +1091,7 @@ static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int 
   // groups per row: plain mosaics count them from the aligned address at or below the row start (up to 7 elements
   // before it), chunk order from column 0
   const int groups_per_row = chunk_h != 0 ? out_w / 8 : (mosaic_w + 7 + 7) / 8;
-  const dim3 grid((groups_per_row + 64 * GX - 1) / (64 * GX), (row_end - row0 + kBH - 1) / kBH, n_planes);
+  const dim3 grid((groups_per_row + 64 * GX * kWX - 1) / (64 * GX * kWX), (row_end - row0 + kBH - 1) / kBH, n_planes);
   MS_REQUIRE((int64_t)grid.x * grid.y * grid.z < (1ll << 30), MISTITCH_ERR_UNSUPPORTED, "mosaic too large for one launch");
   const int64_t n_blocks = (int64_t)grid.x * grid.y * grid.z;
   int rc;
@@ -1089,7 +1101,7 @@ static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int 
     MS_REQUIRE(bins_bytes + 16 <= kStaticScratchBytes, MISTITCH_ERR_UNSUPPORTED,
                "mistitch_fuse_static: %lld output blocks of %d x %d pixels need %zu bytes of tile lists, the static "
                "workspace holds %zu (about %lld blocks): fuse fewer rows per call, or call mistitch_fuse",
-               (long long)n_blocks, kBH, 512 * GX, bins_bytes + 16, kStaticScratchBytes,
+               (long long)n_blocks, kBH, 512 * GX * kWX, bins_bytes + 16, kStaticScratchBytes,
                (long long)((kStaticScratchBytes - 16) / ((kMaxCand + 1) * sizeof(int32_t))));
   } else {
     if ((rc = ctx->bins.reserve(bins_bytes + 16))) return rc;
@@ -1102,7 +1114,7 @@ static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int 
   const int64_t n_bin_groups = (int64_t)grid.x * ((grid.y + kBinRows - 1) / kBinRows) * grid.z;
   MS_LAUNCH(ctx, "k_fuse_bins", k_fuse_bins, dim3((unsigned)((n_bin_groups + 3) / 4)), dim3(256), 0, n_tiles, tile_h, tile_w,
             tile_yx, tile_plane, reinterpret_cast<int32_t*>(ws), (int)grid.x, (int)grid.y, n_planes, mosaic_w,
-            row0, row_end, 512 * GX, ff_safe);
+            row0, row_end, 512 * GX * kWX, ff_safe);
   if (ff_type == MISTITCH_FF_F32 && n_tiles > 0)
     MS_LAUNCH(ctx, "k_ff_check", k_ff_check, dim3(kFfChunks, kFfPlanes), dim3(256), 0,
               reinterpret_cast<const float*>(flatfields), tile_ff, n_tiles, (int64_t)tile_h * tile_w, ff_safe);

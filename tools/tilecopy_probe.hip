@@ -195,6 +195,14 @@ __global__ __launch_bounds__(256) void k_tile_row1(const uint16_t* __restrict__ 
     } else if constexpr (FFMODE == 3) {
       ff[0] = *reinterpret_cast<const f4*>(f);
       ff[1] = ff[0];
+    } else if constexpr (FFMODE == 4) {  // every flatfield load falls into one 8 KiB row: served by the CU's L1
+      const float* g = ffs + 8 * j;
+      ff[0] = *reinterpret_cast<const f4*>(g);
+      ff[1] = *reinterpret_cast<const f4*>(g + 4);
+    } else if constexpr (FFMODE == 5) {  // a 512 KiB window (64 rows): served by L2, never by L1
+      const float* g = ffs + (size_t)(ly & 63) * T + 8 * j;
+      ff[0] = *reinterpret_cast<const f4*>(g);
+      ff[1] = *reinterpret_cast<const f4*>(g + 4);
     } else {
       ff[0] = *reinterpret_cast<const f4*>(f);
       ff[1] = *reinterpret_cast<const f4*>(f + 4);
@@ -432,6 +440,8 @@ int main() {
   run("1 group/lane, one tile row per WG, ff mem", [&] { k_tile_row1<true, 0, 0><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
   run("  the same, contiguous ff loads (timing)", [&] { k_tile_row1<true, 0, 0, 1><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
   run("  the same, non-temporal ff loads", [&] { k_tile_row1<true, 0, 0, 2><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
+  run("  the same, ff loads hit L1 (timing)", [&] { k_tile_row1<true, 0, 0, 4><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
+  run("  the same, ff loads hit L2 only (timing)", [&] { k_tile_row1<true, 0, 0, 5><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
   run("  the same, half the ff bytes (timing)", [&] { k_tile_row1<true, 0, 0, 3><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
   run("1 group/lane, one tile row per WG, no ff", [&] { k_tile_row1<false, 0, 0><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
   run("1 group/lane, one tile row per WG, ff mem", [&] { k_tile_row1<true, 0, 0><<<n_rows_all, 256>>>(tiles, ffs, dyx, mosaic, Hm, Wm); });
