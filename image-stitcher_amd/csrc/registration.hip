@@ -2174,11 +2174,7 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
     const cx<T>* slab = Rs + (slab_pos[min(slab0 + ns, n_slabs - 1)] / kSlab) * sp;
     double* dst = rows + ns * slab_elems;
     constexpr int U = 8;  // loads in flight per lane: one at a time would leave the workgroup waiting on memory
-#if defined(MS_UPS_ABLATE) && MS_UPS_ABLATE == 1  /* measurement build: no slab loads */
-    for (int e0 = tid; e0 < 0; e0 += kThreads * U) {
-#else
     for (int e0 = tid; e0 < Sr * kSlab; e0 += kThreads * U) {
-#endif
       cx<T> v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) v[u] = slab[min(e0 + u * kThreads, Sr * kSlab - 1)];
@@ -2226,15 +2222,7 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
   }
 #pragma unroll
   for (int ns = 0; ns < NS; ++ns) acc[ns] = d4{0.0, 0.0, 0.0, 0.0};
-#if defined(MS_UPS_ABLATE) && MS_UPS_ABLATE == 2  /* measurement build: no products */
-  if (nsteps > 1000000) {
-#elif defined(MS_UPS_ABLATE) && MS_UPS_ABLATE == 3  /* measurement build: an eighth of the products */
-  const int nsteps_all = nsteps;
   if (nsteps > 0) {
-#define nsteps (nsteps_all / 8)
-#else
-  if (nsteps > 0) {
-#endif
     const double* brow = rows + (2 * step0 + kk_off) * (2 * kSlab) + bcol;
     double nb[NS];  // the next step's operands are read from LDS while this step's products run
 #pragma unroll
@@ -2251,7 +2239,6 @@ __global__ __launch_bounds__(kThreads) void k_ups_short(const PairDesc* desc, co
       for (int ns = 0; ns < NS; ++ns) acc[ns] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[ns], acc[ns], 0, 0, 0);
       w = rotate(w, step2);
     }
-#undef nsteps
   }
   __syncthreads();  // every wave has read its last row: the slabs make room for the second half's sums
   double* red = rows;  // [tile][slab][register][lane]
