@@ -299,17 +299,18 @@ def main():
     ff_type = _lib.FF_F32 if ffs is not None else _lib.FF_NONE
     gathered = [None, None]
 
-    def register(flags, out, status):
+    def register(flags, out, status, use_ctx=None):
         """Flatfield-correct the registration channel and register this rank's pairs: with a flatfield the
         strips are corrected as they are extracted (one call), which equals correcting whole tiles first."""
         if n_pairs == 0:
             return
+        handle = (use_ctx or ctx).handle
         if ffs is not None:
-            check(lib.mistitch_register_pairs_flatfield(ctx.handle, ptr(tiles[0]), n_local, tile, tile, tile * tile,
+            check(lib.mistitch_register_pairs_flatfield(handle, ptr(tiles[0]), n_local, tile, tile, tile * tile,
                                                         ptr(ffs[0]), ff_type, ptr(d_pair_idx), ptr(d_pair_dir),
                                                         n_pairs, edge, flags, ptr(out), ptr(status)))
         else:
-            check(lib.mistitch_register_pairs(ctx.handle, ptr(tiles[0]), n_local, tile, tile, tile * tile,
+            check(lib.mistitch_register_pairs(handle, ptr(tiles[0]), n_local, tile, tile, tile * tile,
                                               ptr(d_pair_idx), ptr(d_pair_dir), n_pairs, edge, flags,
                                               ptr(out), ptr(status)))
 
@@ -369,6 +370,29 @@ def main():
         step_fusion()
     t_reg = timed(step_registration, args.steps)
     t_fuse = timed(step_fusion, args.steps)
+    # The registration step replayed from a HIP graph (one-GPU and as-rank runs; never `value`): after a sizing call the
+    # library only enqueues kernels, so the whole call is captured once on a stream of its own and replayed - what is
+    # left of the gaps between its ten launches, which matter at a rank's share of an 8-way split (a step under 1 ms).
+    graph_fig = None
+    if world == 1 and not args.no_side and n_pairs > 0:
+        g_stream = torch.cuda.Stream(device)
+        g_ctx = _lib.Context(local_rank, g_stream.cuda_stream, pair_chunk=args.pair_chunk)
+        g_out, g_status = torch.empty_like(d_out), torch.empty_like(d_status)
+        with torch.cuda.stream(g_stream):
+            register(fft_flag, g_out, g_status, g_ctx)   # sizes that context's workspaces
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=g_stream):
+            register(fft_flag, g_out, g_status, g_ctx)
+        g_out.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        same = bool(torch.equal(g_out, d_out) and torch.equal(g_status, d_status))
+        t_graph = timed(graph.replay, args.steps)
+        graph_fig = {"ms_per_step": round(1e3 * t_graph / args.steps, 3), "eager_ms_per_step": round(1e3 * t_reg / args.steps, 3),
+                     "rows_equal_the_eager_step": same,
+                     "what": "mistitch_register_pairs captured once into a HIP graph (torch.cuda.CUDAGraph on a stream of its own) and replayed"}
+        del graph, g_ctx
     # side figures (one-GPU runs): the other fusion mode and the other FFT precision, same bracketing
     side = not args.no_side and world == 1 and not as_rank
     if side:
@@ -606,6 +630,8 @@ def main():
         }
         if shares is not None:
             line["ranks"] = shares
+        if graph_fig is not None:
+            line["registration_graph_replay"] = graph_fig
         if as_rank:
             line["as_rank"] = {"rank": part_rank, "of": part_world, "pairs": n_pairs, "mosaic_rows": band_h, "tiles_resident": n_local,
                                "registration_ms": round(1e3 * t_reg / args.steps, 3), "fusion_ms": round(1e3 * t_fuse / args.steps, 3)}
