@@ -555,6 +555,7 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
   constexpr int kQueue = kBH * 64 * GX * kWX;
   constexpr int kGroupBits = (64 * GX * kWX <= 256) ? 8 : (64 * GX * kWX <= 512 ? 9 : 10);  // group in the block row, then the row
   static_assert(64 * GX * kWX <= 1024 && kBH <= (1 << (13 - kGroupBits)), "13 bits of group and row");
+  static_assert(GX <= 6, "a lane's copy sources are packed 5 bits per group into one word");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wx = wave % kWX, wy = wave / kWX;
   if (tid == 0) queue_len[0] = queue_len[1] = 0;
