@@ -37,6 +37,7 @@ EXPORTS = [
     "mistitch_set_upsample_factor", "mistitch_pyramid", "mistitch_chunk_layout", "mistitch_refine_pairs",
     "mistitch_register_pairs_flatfield", "mistitch_fuse_static", "mistitch_register_pairs_candidates",
     "mistitch_bitshuffle", "mistitch_fuse_chunked", "mistitch_pyramid_chunked", "mistitch_set_pixel_max",
+    "mistitch_pyramid_to_chunks",
 ]
 
 
@@ -79,6 +80,7 @@ def _load() -> C.CDLL:
         "mistitch_mip": [vp, vp, i32, i64, i64, vp],
         "mistitch_pyramid": [vp, vp, i32, i32, i32, i32, C.POINTER(vp)],
         "mistitch_pyramid_chunked": [vp, vp, i32, i32, i32, i32, i32, i32, C.POINTER(vp)],
+        "mistitch_pyramid_to_chunks": [vp, vp, i32, i32, i32, i32, i32, i32, i32, C.POINTER(vp)],
         "mistitch_chunk_layout": [vp, vp, i32, i32, i32, i32, i32, i32, vp],
         "mistitch_bitshuffle": [vp, vp, vp, i64, i32, i64],
         "mistitch_synchronize": [vp],

@@ -932,7 +932,36 @@ __global__ __launch_bounds__(256) void k_mip(const uint16_t* __restrict__ in, in
 constexpr int kPyrTileH = 64, kPyrTileW = 256, kPyrMaxLevels = 7;
 struct PyrLevels {
   double* out[kPyrMaxLevels];  // [l]: level l (index 0 unused)
+  int och, ocw;                // chunk shape of the LEVELS when they are written in chunk order (0: row-major planes)
+  // where pixel (oy, ox) of plane `plane` of a level of Hl x Wl pixels goes
+  __device__ __forceinline__ int64_t at(int plane, int Hl, int Wl, int oy, int ox) const {
+    if (och == 0) return ((int64_t)plane * Hl + oy) * Wl + ox;
+    const int ncy = (Hl + och - 1) / och, ncx = (Wl + ocw - 1) / ocw;
+    return (((int64_t)plane * ncy + oy / och) * ncx + ox / ocw) * ((int64_t)och * ocw) + (int64_t)(oy % och) * ocw + ox % ocw;
+  }
 };
+
+// Zeros in what sticks out of a level written in chunk order: the rows below the level and the columns right of it,
+// up to whole chunks.  grid (blocks, levels - 1, planes), grid-stride over the padding elements of a plane.
+__global__ __launch_bounds__(256) void k_pyramid_padding(int H, int W, PyrLevels lv) {
+  const int l = 1 + blockIdx.y, plane = blockIdx.z;
+  const int Hl = H >> l, Wl = W >> l;
+  if (Hl == 0 || Wl == 0 || lv.out[l] == nullptr) return;
+  const int Hp = (Hl + lv.och - 1) / lv.och * lv.och, Wp = (Wl + lv.ocw - 1) / lv.ocw * lv.ocw;
+  const int64_t right = (int64_t)Hl * (Wp - Wl), below = (int64_t)(Hp - Hl) * Wp;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < right + below; e += (int64_t)gridDim.x * blockDim.x) {
+    int oy, ox;
+    if (e < right) {
+      oy = (int)(e / (Wp - Wl));
+      ox = Wl + (int)(e % (Wp - Wl));
+    } else {
+      const int64_t f = e - right;
+      oy = Hl + (int)(f / Wp);
+      ox = (int)(f % Wp);
+    }
+    lv.out[l][lv.at(plane, Hl, Wl, oy, ox)] = 0.0;
+  }
+}
 
 // `cg`: the image is an array of chunks (ChunkGeom, chunk_w a multiple of 8) instead of row-major planes.
 __global__ __launch_bounds__(256) void k_pyramid(const uint16_t* __restrict__ image, int H, int W, int n_levels,
@@ -964,12 +993,15 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint16_t* __restrict__ im
     }
     const int H1 = H >> 1, W1 = W >> 1;
     const int oy = y >> 1, ox = x >> 1;
+    // (chunk order) the four values of a cell lie side by side unless a chunk ends among them
+    const bool one_run = lv.och == 0 || ox % lv.ocw + 3 < lv.ocw;
+    const int64_t first = (n_levels > 1 && oy < H1 && ox < W1) ? lv.at(plane, H1, W1, oy, ox) : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const unsigned sum = px[0][2 * i] + px[0][2 * i + 1] + px[1][2 * i] + px[1][2 * i + 1];
       sums[0][j][4 * g + i] = sum;
       if (n_levels > 1 && oy < H1 && ox + i < W1)
-        lv.out[1][((int64_t)plane * H1 + oy) * W1 + ox + i] = (double)sum * 0.25;
+        lv.out[1][one_run ? first + i : lv.at(plane, H1, W1, oy, ox + i)] = (double)sum * 0.25;
     }
   }
   int cur = 0, th = kPyrTileH / 2, tw = kPyrTileW / 2;  // extent of the sums held in sums[cur]
@@ -984,7 +1016,7 @@ __global__ __launch_bounds__(256) void k_pyramid(const uint16_t* __restrict__ im
                            sums[cur][2 * j + 1][2 * i + 1];
       sums[cur ^ 1][j][i] = sum;
       const int oy = (y0 >> l) + j, ox = (x0 >> l) + i;
-      if (oy < Hl && ox < Wl) lv.out[l][((int64_t)plane * Hl + oy) * Wl + ox] = (double)sum * scale;
+      if (oy < Hl && ox < Wl) lv.out[l][lv.at(plane, Hl, Wl, oy, ox)] = (double)sum * scale;
     }
     cur ^= 1;
     th = nh;
@@ -1219,13 +1251,15 @@ extern "C" int mistitch_apply_flatfield(mistitch_ctx* ctx, const uint16_t* in, c
 }
 
 static int pyramid_impl(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int h, int w, int n_levels,
-                        double* const* levels, int chunk_h, int chunk_w) {
+                        double* const* levels, int chunk_h, int chunk_w, int out_chunk_h = 0, int out_chunk_w = 0) {
   MS_REQUIRE(ctx && image && levels, MISTITCH_ERR_ARG, "NULL argument");
   MS_REQUIRE(n_planes > 0 && h > 0 && w > 0, MISTITCH_ERR_ARG, "bad geometry");
   MS_REQUIRE(n_levels >= 1 && n_levels <= kPyrMaxLevels, MISTITCH_ERR_UNSUPPORTED, "n_levels must be in [1, %d]",
              kPyrMaxLevels);
   if (n_levels == 1) return MISTITCH_OK;  // level 0 is the image itself
   PyrLevels lv{};
+  lv.och = out_chunk_h;
+  lv.ocw = out_chunk_w;
   for (int l = 1; l < n_levels; ++l) {
     MS_REQUIRE(levels[l] != nullptr || (h >> l) == 0 || (w >> l) == 0, MISTITCH_ERR_ARG, "levels[%d] is NULL", l);
     lv.out[l] = levels[l];
@@ -1241,6 +1275,8 @@ static int pyramid_impl(mistitch_ctx* ctx, const uint16_t* image, int n_planes, 
     MS_REQUIRE((int64_t)cg.ncx * chunk_h * chunk_w < (1ll << 31), MISTITCH_ERR_UNSUPPORTED, "a row of chunks of 2^31 elements or more");
   }
   MS_LAUNCH(ctx, "k_pyramid", k_pyramid, grid, dim3(256), 0, image, h, w, n_levels, lv, cg);
+  if (out_chunk_h != 0)
+    MS_LAUNCH(ctx, "k_pyramid_padding", k_pyramid_padding, dim3(1024, n_levels - 1, n_planes), dim3(256), 0, h, w, lv);
   MS_HIP(hipGetLastError());
   return MISTITCH_OK;
 }
@@ -1254,6 +1290,15 @@ extern "C" int mistitch_pyramid_chunked(mistitch_ctx* ctx, const uint16_t* chunk
                                         int chunk_w, int n_levels, double* const* levels) {
   MS_REQUIRE(chunk_h > 0 && chunk_w > 0, MISTITCH_ERR_ARG, "bad chunk shape %d x %d", chunk_h, chunk_w);
   return pyramid_impl(ctx, chunks, n_planes, h, w, n_levels, levels, chunk_h, chunk_w);
+}
+
+extern "C" int mistitch_pyramid_to_chunks(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int h, int w,
+                                          int chunk_h, int chunk_w, int image_is_chunked, int n_levels,
+                                          double* const* levels) {
+  MS_REQUIRE(chunk_h > 0 && chunk_w > 0, MISTITCH_ERR_ARG, "bad chunk shape %d x %d", chunk_h, chunk_w);
+  MS_REQUIRE(n_planes > 0 && n_planes < 65536, MISTITCH_ERR_UNSUPPORTED, "%d planes", n_planes);
+  return pyramid_impl(ctx, image, n_planes, h, w, n_levels, levels, image_is_chunked ? chunk_h : 0,
+                      image_is_chunked ? chunk_w : 0, chunk_h, chunk_w);
 }
 
 // ---- chunk layout for the array writer ---------------------------------------------------------

@@ -116,17 +116,47 @@ def compute_mip(tiles):
     return out.cpu().numpy() if is_np else out
 
 
-def generate_pyramid(image, num_levels: int, chunked_hw: Optional[Tuple[int, int]] = None):
+def generate_pyramid(image, num_levels: int, chunked_hw: Optional[Tuple[int, int]] = None,
+                     level_chunks: Optional[Tuple[int, int]] = None):
     """[image, level 1, ..., level num_levels-1] as Stitcher.generate_pyramid builds it
     (stitcher.py:652-668): level l is the float64 mean over 2^l x 2^l blocks of the two
     last axes, excess rows / columns trimmed.  ``image`` is uint16 with any leading axes.
     ``chunked_hw`` = (h, w): ``image`` is a mosaic born in chunk order, ``[..., ncy, ncx, chunk_h, chunk_w]`` of an
-    h x w mosaic (``fuse_tiles(chunks=...)``); the levels come out as row-major planes all the same."""
+    h x w mosaic (``fuse_tiles(chunks=...)``); the levels come out as row-major planes all the same.
+    ``level_chunks`` = (chunk_h, chunk_w): the LEVELS come out in chunk order too,
+    ``[..., ceil(h_l / chunk_h), ceil(w_l / chunk_w), chunk_h, chunk_w]`` with zeros beyond the level (what
+    ``omezarr.chunk_layout`` makes of a row-major level); a chunk-ordered ``image`` must have the same chunk shape."""
     import ctypes as C
 
     torch = _torch()
     is_np = not isinstance(image, torch.Tensor)
     img = to_device_u16(image)
+    if level_chunks is not None:
+        ch, cw = int(level_chunks[0]), int(level_chunks[1])
+        if ch <= 0 or cw <= 0:
+            raise ValueError("chunk shape must be positive")
+        if chunked_hw is not None:
+            if img.dim() < 4 or tuple(int(v) for v in img.shape[-2:]) != (ch, cw):
+                raise ValueError(f"a chunk-ordered mosaic for level chunks of {ch} x {cw} must be [..., ncy, ncx, {ch}, {cw}]")
+            h, w = int(chunked_hw[0]), int(chunked_hw[1])
+            if tuple(int(v) for v in img.shape[-4:-2]) != (-(-h // ch), -(-w // cw)):
+                raise ValueError(f"the chunk grid does not hold a {h} x {w} mosaic")
+            lead = tuple(int(v) for v in img.shape[:-4])
+        else:
+            if img.dim() < 2:
+                raise ValueError("image must have at least two axes")
+            h, w = int(img.shape[-2]), int(img.shape[-1])
+            lead = tuple(int(v) for v in img.shape[:-2])
+        planes = int(np.prod(lead)) if lead else 1
+        levels = [torch.empty(lead + (-(-(h >> l) // ch), -(-(w >> l) // cw), ch, cw), dtype=torch.float64, device=img.device)
+                  for l in range(1, int(num_levels))]
+        arr = (C.c_void_p * max(int(num_levels), 1))()
+        for l, t in enumerate(levels, start=1):
+            arr[l] = t.data_ptr() if t.numel() else None
+        check(lib.mistitch_pyramid_to_chunks(_lib.default_context().handle, ptr(img.contiguous()), planes, h, w, ch, cw,
+                                             1 if chunked_hw is not None else 0, int(num_levels), arr))
+        out = [img] + levels
+        return [t.cpu().numpy() for t in out] if is_np else out
     if chunked_hw is not None:
         if img.dim() < 4:
             raise ValueError("a chunk-ordered mosaic has the axes [..., ncy, ncx, chunk_h, chunk_w]")

@@ -152,7 +152,7 @@ def write_ome_zarr(path: str, mosaic, channel_names: Sequence[str], channel_colo
     the others float64 block means, uncompressed).  Returns {"levels": [...shapes], "chunks": (...)}.
     ``chunked_hw`` = (H, W): ``mosaic`` was born in chunk order, [C, Z, ncy, ncx, chunk_h, chunk_w] with the
     reference's chunk shape for these tiles (``fusion.fuse_tiles(chunks=reference_chunks(tile_h, tile_w)[3:])``):
-    level 0 goes to the files as it is, without a layout pass."""
+    level 0 goes to the files as it is and the pyramid levels are born in chunk order as well: no layout pass."""
     torch = _torch()
     from . import fusion
     chunks = reference_chunks(tile_h, tile_w)
@@ -170,7 +170,9 @@ def write_ome_zarr(path: str, mosaic, channel_names: Sequence[str], channel_colo
         raise ValueError("one name and one colour per channel")
     if n_levels is None:
         n_levels = default_pyramid_levels(w, h)
-    levels = fusion.generate_pyramid(mosaic, n_levels, chunked_hw=chunked_hw)   # [mosaic, float64 means ...] on the device
+    # [mosaic, float64 means ...] on the device; the levels of a chunk-ordered mosaic are born in chunk order too
+    levels = fusion.generate_pyramid(mosaic, n_levels, chunked_hw=chunked_hw,
+                                     level_chunks=(ch, cw) if chunked_hw is not None else None)
     os.makedirs(path, exist_ok=True)
     with open(os.path.join(path, ".zgroup"), "w") as f:
         json.dump({"zarr_format": 2}, f)
@@ -184,8 +186,8 @@ def write_ome_zarr(path: str, mosaic, channel_names: Sequence[str], channel_colo
         pool = ThreadPoolExecutor(max_workers=writers)
     try:
         for l, level in enumerate(levels):
-            born_chunked = l == 0 and chunked_hw is not None
-            lh, lw = (h, w) if born_chunked else (int(level.shape[-2]), int(level.shape[-1]))
+            born_chunked = chunked_hw is not None
+            lh, lw = (h >> l, w >> l) if born_chunked else (int(level.shape[-2]), int(level.shape[-1]))
             shape = (1, n_c, n_z, lh, lw)
             shapes.append(shape)
             root = os.path.join(path, str(l))

@@ -329,6 +329,15 @@ int mistitch_pyramid(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int
 int mistitch_pyramid_chunked(mistitch_ctx* ctx, const uint16_t* chunks, int n_planes, int h, int w, int chunk_h,
                              int chunk_w, int n_levels, double* const* levels);
 
+/* mistitch_pyramid with every LEVEL written in chunk order as well: levels[l] receives
+ * [n_planes][ceil((h >> l) / chunk_h)][ceil((w >> l) / chunk_w)][chunk_h][chunk_w] float64, what sticks out of the
+ * level zero - the buffers the reference's per-level da.store hands to its chunk files (stitcher.py:526-594) without a
+ * layout pass over the float64 levels (the first one of a 4 x 37k x 37k mosaic is 11 GB).  `image` is row-major planes,
+ * or the chunk-ordered mosaic of mistitch_fuse_chunked when image_is_chunked is non-zero (same chunk shape, chunk_w a
+ * multiple of 8 then).                                                                                        */
+int mistitch_pyramid_to_chunks(mistitch_ctx* ctx, const uint16_t* image, int n_planes, int h, int w, int chunk_h,
+                               int chunk_w, int image_is_chunked, int n_levels, double* const* levels);
+
 /* The planes of an image, [n_planes][h][w] of uint16 (elem_size 2) or float64 (elem_size 8:
  * the pyramid levels), laid out as the chunks a Zarr array with chunks (1, 1, 1, chunk_h,
  * chunk_w) stores them: out[plane][cy][cx][chunk_h][chunk_w], cy < ceil(h / chunk_h),

@@ -169,3 +169,40 @@ def test_store_of_a_mosaic_born_in_chunk_order_equals_the_plain_one(tmp_path):
     cmp = filecmp.dircmp(a, b)
     assert not cmp.left_only and not cmp.right_only
     assert filecmp.cmp(os.path.join(a, "0", "0", "1", "0", "1", "1"), os.path.join(b, "0", "0", "1", "0", "1", "1"), shallow=False)
+    # every file of every level, byte for byte (the pyramid levels of the chunk-ordered mosaic are born in chunk order
+    # too: their padding must be the zeros the layout pass writes)
+    n_files = 0
+    for root, _, files in os.walk(a):
+        for name in files:
+            other = os.path.join(b, os.path.relpath(os.path.join(root, name), a))
+            assert filecmp.cmp(os.path.join(root, name), other, shallow=False), other
+            n_files += 1
+    assert n_files > 3 * 2 + 5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,chunks,levels", [((2, 300, 520), (128, 256), 4), ((1, 1, 257, 263), (64, 64), 5),
+                                                 ((3, 128, 256), (128, 256), 3), ((1, 70, 40), (16, 8), 7)])
+def test_pyramid_levels_born_in_chunk_order_equal_the_laid_out_levels(shape, chunks, levels):
+    """generate_pyramid(level_chunks=...) against chunk_layout of the row-major levels, padding included, from a
+    row-major mosaic and from a chunk-ordered one."""
+    import torch
+    from image_stitcher_amd import fusion
+    rng = np.random.default_rng(shape[-1])
+    img = torch.from_numpy(rng.integers(0, 65536, size=shape, dtype=np.uint16).view(np.int16)).cuda().view(torch.uint16)
+    ch, cw = chunks
+    h, w = shape[-2:]
+    plain = fusion.generate_pyramid(img, levels)
+    for born in (fusion.generate_pyramid(img, levels, level_chunks=chunks),
+                 fusion.generate_pyramid(omezarr.chunk_layout(img.reshape(-1, h, w), ch, cw).reshape(shape[:-2] + (-(-h // ch), -(-w // cw), ch, cw)),
+                                         levels, chunked_hw=(h, w), level_chunks=chunks) if cw % 8 == 0 else None):
+        if born is None:
+            continue
+        assert len(born) == levels
+        for l in range(1, levels):
+            lh, lw = h >> l, w >> l
+            assert tuple(born[l].shape[-4:]) == (-(-lh // ch), -(-lw // cw), ch, cw)
+            if lh == 0 or lw == 0:
+                continue
+            want = omezarr.chunk_layout(plain[l].reshape(-1, lh, lw), ch, cw)
+            assert torch.equal(born[l].reshape(want.shape), want), (l, shape)
