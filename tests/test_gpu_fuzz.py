@@ -15,7 +15,7 @@ spec.loader.exec_module(fz)
 CASES = {"registration": 150, "fusion": 150, "subpixel": 80, "refine": 80, "fusion_wide": 60, "registration_big": 12,
          "apis": 150, "pipeline": 60, "registration_tiny": 400, "fusion_tiny": 300,
          "featureless": 300, "registration_wild": 200, "fusion_ff_extreme": 300, "mixed_radix": 100, "peaks10": 100,
-         "window": 100, "consensus": 150, "fusion_chunked": 200, "u8": 150, "bitshuffle": 150, "subpixel_raw": 120}
+         "window": 100, "consensus": 150, "fusion_chunked": 200, "u8": 150, "bitshuffle": 150, "subpixel_raw": 120, "pyramid_chunks": 150}
 
 
 @pytest.mark.parametrize("kind", sorted(CASES))
@@ -45,7 +45,8 @@ def test_random_inputs_agree_with_the_oracle(kind):
            "consensus": lambda: fz.fuzz_consensus(rng, reg, oreg, synth),
            "fusion_chunked": lambda: fz.fuzz_fusion_chunked(rng, fu, ofu, synth),
            "u8": lambda: fz.fuzz_u8(rng, fu, ofu, synth),
-           "bitshuffle": lambda: fz.fuzz_bitshuffle(rng, fu, ofu, synth)}[kind]
+           "bitshuffle": lambda: fz.fuzz_bitshuffle(rng, fu, ofu, synth),
+           "pyramid_chunks": lambda: fz.fuzz_pyramid_chunks(rng, fu, ofu, synth)}[kind]
     for i in range(CASES[kind]):
         good, desc, _ = run()
         assert good, (i, desc)

@@ -579,6 +579,43 @@ def fuzz_bitshuffle(rng, fu, ofu, synth):
         (got[None, None], want[None, None], np.zeros((0, 2)), np.zeros(0))
 
 
+def fuzz_pyramid_chunks(rng, fu, ofu, synth):
+    """Pyramid levels born in chunk order against the row-major levels laid out by the layout kernel (padding included)
+    and against NumPy block means; row-major and chunk-ordered mosaics, any plane count, size, chunk shape and depth."""
+    import torch
+    from image_stitcher_amd import omezarr
+    planes = int(rng.integers(1, 4))
+    h, w = int(rng.integers(1, 400)), int(rng.integers(1, 700))
+    ch = int(rng.choice([1, 7, 16, 64, 128, int(rng.integers(1, 200))]))
+    cw = int(rng.choice([8, 16, 64, 256, 8 * int(rng.integers(1, 40))])) if rng.random() < 0.7 else int(rng.integers(1, 300))
+    levels = int(rng.integers(1, 8))
+    img_np = rng.integers(0, 65536, size=(planes, h, w), dtype=np.uint16)
+    img = torch.from_numpy(img_np.view(np.int16)).cuda().view(torch.uint16)
+    plain = fu.generate_pyramid(img, levels)
+    chunked_in = cw % 8 == 0 and rng.random() < 0.5
+    if chunked_in:
+        laid = omezarr.chunk_layout(img, ch, cw)
+        born = fu.generate_pyramid(laid, levels, chunked_hw=(h, w), level_chunks=(ch, cw))
+    else:
+        born = fu.generate_pyramid(img, levels, level_chunks=(ch, cw))
+    good = len(born) == levels
+    got = want = np.zeros((1, 1, 1))
+    for l in range(1, levels):
+        lh, lw = h >> l, w >> l
+        if lh == 0 or lw == 0:
+            good = good and born[l].numel() == 0
+            continue
+        ref = img_np[:, :lh << l, :lw << l].astype(np.float64).reshape(planes, lh, 1 << l, lw, 1 << l).mean(axis=(2, 4))
+        good = good and np.array_equal(plain[l].cpu().numpy(), ref)
+        exp = omezarr.chunk_layout(plain[l], ch, cw)
+        if not torch.equal(born[l].reshape(exp.shape), exp):
+            good = False
+            got, want = born[l].reshape(exp.shape).cpu().numpy().reshape(planes, -1, ch * cw), exp.cpu().numpy().reshape(planes, -1, ch * cw)
+            break
+    return bool(good), dict(kind="pyramid_chunks", planes=planes, size=(h, w), chunks=(ch, cw), levels=levels, chunked_in=chunked_in), \
+        (got, want, np.zeros((0, 2)), np.zeros(0))
+
+
 def fuzz_fusion_wide(rng, fu, ofu, synth):
     """Mosaics several blocks wide and tall (a block is 32 rows by 2048 pixels), few tall tiles."""
     th, tw = int(rng.integers(8, 120)), int(rng.integers(200, 1700))
@@ -634,7 +671,8 @@ def main():
                "consensus": lambda: fuzz_consensus(rng, reg, oreg, synth),
                "fusion_chunked": lambda: fuzz_fusion_chunked(rng, fu, ofu, synth),
                "u8": lambda: fuzz_u8(rng, fu, ofu, synth),
-               "bitshuffle": lambda: fuzz_bitshuffle(rng, fu, ofu, synth)}
+               "bitshuffle": lambda: fuzz_bitshuffle(rng, fu, ofu, synth),
+               "pyramid_chunks": lambda: fuzz_pyramid_chunks(rng, fu, ofu, synth)}
     kinds = [k for k in runners if not args.only or k in args.only.split(",")]
     counts = {k: 0 for k in kinds}
     last = t0
