@@ -224,9 +224,12 @@ def main():
 
     # The CPU baseline runs FIRST, on rank 0 of a one-GPU run: its worker processes are started
     # before this process has touched the GPU.
-    cpu = None
+    cpu, cpu_error = None, None
     if rank == 0 and world == 1 and args.cpu_pairs > 0:
-        cpu = cpu_baseline(args.cpu_pairs, edge, tile, args.fuse_mode, cfg["flatfield"])
+        try:   # a host-side failure (worker processes, memory) is reported in the line, it does not end the GPU run
+            cpu = cpu_baseline(args.cpu_pairs, edge, tile, args.fuse_mode, cfg["flatfield"])
+        except Exception as exc:  # noqa: BLE001 - reported, not raised
+            cpu_error = f"{type(exc).__name__}: {exc}"[:300]
 
     import torch
     import torch.distributed as dist
@@ -679,6 +682,8 @@ def main():
                         "start point and is not run",
                 "planted_integer_shifts_recovered": bool((st4_np == 0).all() and
                                                          np.array_equal(np.rint(out4_np[:, 1:]).astype(np.int64), expected))}
+        if cpu_error is not None:
+            line["cpu_baseline"] = {"error": cpu_error}
         if cpu is not None:
             cpu_pairs_s = cpu["pairs"] / cpu["t_reg"]
             line["cpu_baseline"] = {
