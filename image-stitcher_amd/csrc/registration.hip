@@ -460,86 +460,168 @@ __device__ __forceinline__ unsigned ff_corrected(unsigned v, const void* ff, int
   }
 }
 
+// trunc(clip(v / f)) with the flatfield value in hand.
+template <int FF, typename F>
+__device__ __forceinline__ unsigned ff_corrected_by(unsigned v, F f, unsigned vmax) {
+  if constexpr (FF == MISTITCH_FF_F32) {
+    const float q = __fdiv_rn((float)v, (float)f);
+    return (unsigned)fminf(fmaxf(q, 0.0f), (float)vmax);
+  } else {
+    const double q = (double)v / (double)f;
+    return (unsigned)fmin(fmax(q, 0.0), (double)vmax);
+  }
+}
+
 // Strip extraction with the flatfield applied on the way: both strips of every pair go to
 // the staging buffer in canonical [S][L] layout (left strips transposed), corrected as
 // load_batch_images corrects whole tiles before the reference cuts its edges
 // (tile_registration.py:2184-2279).  Only a quarter of the pixels of a tile lie in strips.
 // Long sides multiples of 64, 16-byte aligned rows.  EDGE: the short side (the edge width) is arbitrary;
 // the left strips then start at an unaligned column and are read pixel by pixel.
-// grid (max L / 64, ceil(max S / 64), 2 * pairs_in_pass).
+// Every pair of a direction cuts the same pixels of its tiles, so the flatfield values of a 64 x 64 piece of a strip
+// are the same for all of them: a workgroup keeps its 16 values per lane in registers and takes the pairs of a
+// group of kStagePairs in turn (the flatfield is then read once per group, not once per pair).
+// grid (max L / 64, ceil(max S / 64), 4 * ceil(pairs_in_pass / kStagePairs)): z = 4 group + 2 direction + strip.
+#ifndef MS_STAGE_PAIRS
+#define MS_STAGE_PAIRS 16
+#endif
+constexpr int kStagePairs = MS_STAGE_PAIRS;
 template <int FF, bool EDGE>
 __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, int64_t tile_pitch, int H, int W,
                                                         int w_left, int w_top, const int32_t* pair_idx,
                                                         const PairDesc* desc, const int8_t* status, int pair0,
-                                                        const void* __restrict__ ff, unsigned vmax) {
+                                                        int n_in_pass, const void* __restrict__ ff, unsigned vmax) {
+  using FT = typename std::conditional<FF == MISTITCH_FF_F32, float, double>::type;
   __shared__ uint16_t tile[64][64 + 2];
-  const int p = pair0 + (blockIdx.z >> 1), which = blockIdx.z & 1;
-  if (status[p] != MISTITCH_PAIR_OK) return;
-  const PairDesc d = desc[p];
+  const int which = blockIdx.z & 1, dir = (blockIdx.z >> 1) & 1;  // dir 1: left pairs (strips transposed)
+  const int p_begin = pair0 + (int)(blockIdx.z >> 2) * kStagePairs, p_end = min(pair0 + n_in_pass, p_begin + kStagePairs);
+  const int S = dir ? w_left : w_top, L = dir ? H : W;
   const int l0 = blockIdx.x * 64, s0 = blockIdx.y * 64;
-  if (l0 >= d.L || s0 >= d.S) return;
-  const uint16_t* img = tiles + (int64_t)pair_idx[2 * p + which] * tile_pitch;
-  uint16_t* dst = const_cast<uint16_t*>(which == 0 ? d.a : d.b);
+  if (l0 >= L || s0 >= S) return;
+  const FT* ffv = reinterpret_cast<const FT*>(ff);
   const int t = threadIdx.x, sub = t & 7, row = t >> 3;  // 8 lanes cover one 128-byte row segment
-  if (d.transposed) {
+  if (dir) {
     // image rows l0 .. l0+63, image columns x0 + s0 .. +63
     const int x0 = (which == 0 ? W - w_left : 0) + s0;
+    FT fr[16];
     if constexpr (EDGE) {
       const int c = t & 63;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int r = (t >> 6) + 4 * i;
-        const int64_t at = (int64_t)(l0 + r) * W + x0 + c;
-        tile[r][c] = s0 + c < d.S ? (uint16_t)ff_corrected<FF>(img[at], ff, at, vmax) : (uint16_t)0;
-      }
+      for (int i = 0; i < 16; ++i) fr[i] = ffv[(int64_t)(l0 + (t >> 6) + 4 * i) * W + x0 + (s0 + c < S ? c : 0)];
     } else {
 #pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) fr[8 * i + q] = ffv[(int64_t)(l0 + row + 32 * i) * W + x0 + 8 * sub + q];
+    }
+    // the next pair of this direction in the group (p_end: none); the same for every lane
+    auto next_pair = [&](int p) {
+      while (p < p_end && (status[p] != MISTITCH_PAIR_OK || desc[p].transposed != dir)) ++p;
+      return p;
+    };
+    uint4 cur[2] = {}, nxt[2] = {};  // (aligned path) the pair's pixels, requested one pair ahead
+    auto fetch = [&](int p, uint4 (&v)[2]) {
+      const uint16_t* img = tiles + (int64_t)pair_idx[2 * p + which] * tile_pitch;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) v[i] = *reinterpret_cast<const uint4*>(img + (int64_t)(l0 + row + 32 * i) * W + x0 + 8 * sub);
+    };
+    int p = next_pair(p_begin);
+    if (!EDGE && p < p_end) fetch(p, cur);
+    for (; p < p_end;) {
+      const int pn = next_pair(p + 1);
+      if (!EDGE && pn < p_end) fetch(pn, nxt);
+      const PairDesc d = desc[p];
+      const uint16_t* img = tiles + (int64_t)pair_idx[2 * p + which] * tile_pitch;
+      uint16_t* dst = const_cast<uint16_t*>(which == 0 ? d.a : d.b);
+      if constexpr (EDGE) {
+        const int c = t & 63;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int r = (t >> 6) + 4 * i;
+          const int64_t at = (int64_t)(l0 + r) * W + x0 + c;
+          tile[r][c] = s0 + c < S ? (uint16_t)ff_corrected_by<FF>(img[at], fr[i], vmax) : (uint16_t)0;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint4 v = cur[i];
+          const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+          unsigned* dstw = reinterpret_cast<unsigned*>(&tile[row + 32 * i][8 * sub]);  // rows are 132 bytes: 4-byte aligned
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            dstw[q] = ff_corrected_by<FF>(w4[q] & 0xffffu, fr[8 * i + 2 * q], vmax) |
+                      (ff_corrected_by<FF>(w4[q] >> 16, fr[8 * i + 2 * q + 1], vmax) << 16);
+        }
+      }
+      __syncthreads();
+#pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int y = l0 + row + 32 * i;
-        const int64_t at = (int64_t)y * W + x0 + 8 * sub;
-        const uint4 v = *reinterpret_cast<const uint4*>(img + at);
-        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
-        unsigned* dstw = reinterpret_cast<unsigned*>(&tile[row + 32 * i][8 * sub]);  // rows are 132 bytes: 4-byte aligned
+        const int sline = row + 32 * i;  // output line
+        if (EDGE && s0 + sline >= S) continue;
+        uint4 o;
+        unsigned w4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          dstw[q] = ff_corrected<FF>(w4[q] & 0xffffu, ff, at + 2 * q, vmax) | (ff_corrected<FF>(w4[q] >> 16, ff, at + 2 * q + 1, vmax) << 16);
+          w4[q] = (unsigned)tile[8 * sub + 2 * q][sline] | ((unsigned)tile[8 * sub + 2 * q + 1][sline] << 16);
+        o.x = w4[0];
+        o.y = w4[1];
+        o.z = w4[2];
+        o.w = w4[3];
+        *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + sline) * H + l0 + 8 * sub) = o;
       }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int sline = row + 32 * i;  // output line
-      if (EDGE && s0 + sline >= d.S) continue;
-      uint4 o;
-      unsigned w4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        w4[q] = (unsigned)tile[8 * sub + 2 * q][sline] | ((unsigned)tile[8 * sub + 2 * q + 1][sline] << 16);
-      o.x = w4[0];
-      o.y = w4[1];
-      o.z = w4[2];
-      o.w = w4[3];
-      *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + sline) * H + l0 + 8 * sub) = o;
+      __syncthreads();  // the piece has been read out: the next pair may overwrite it
+      cur[0] = nxt[0];
+      cur[1] = nxt[1];
+      p = pn;
     }
   } else {
     const int y0 = (which == 0 ? H - w_top : 0) + s0;
+    FT fr[16];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int sline = row + 32 * i;
-      if (EDGE && s0 + sline >= d.S) continue;
-      const int64_t at = (int64_t)(y0 + sline) * W + l0 + 8 * sub;
-      const uint4 v = *reinterpret_cast<const uint4*>(img + at);
-      const unsigned w4[4] = {v.x, v.y, v.z, v.w};
-      uint4 o;
-      unsigned r4[4];
+      const int sline = min(row + 32 * i, S - 1 - s0);  // (EDGE: lines past the strip are not stored)
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        r4[q] = ff_corrected<FF>(w4[q] & 0xffffu, ff, at + 2 * q, vmax) | (ff_corrected<FF>(w4[q] >> 16, ff, at + 2 * q + 1, vmax) << 16);
-      o.x = r4[0];
-      o.y = r4[1];
-      o.z = r4[2];
-      o.w = r4[3];
-      *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + sline) * W + l0 + 8 * sub) = o;
+      for (int q = 0; q < 8; ++q) fr[8 * i + q] = ffv[(int64_t)(y0 + sline) * W + l0 + 8 * sub + q];
+    }
+    auto next_pair = [&](int p) {
+      while (p < p_end && (status[p] != MISTITCH_PAIR_OK || desc[p].transposed != dir)) ++p;
+      return p;
+    };
+    uint4 cur[2] = {}, nxt[2] = {};  // the pair's pixels, requested one pair ahead (lines past the strip: the last line's)
+    auto fetch = [&](int p, uint4 (&v)[2]) {
+      const uint16_t* img = tiles + (int64_t)pair_idx[2 * p + which] * tile_pitch;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        v[i] = *reinterpret_cast<const uint4*>(img + (int64_t)(y0 + min(row + 32 * i, S - 1 - s0)) * W + l0 + 8 * sub);
+    };
+    int p = next_pair(p_begin);
+    if (p < p_end) fetch(p, cur);
+    for (; p < p_end;) {
+      const int pn = next_pair(p + 1);
+      if (pn < p_end) fetch(pn, nxt);
+      const PairDesc d = desc[p];
+      uint16_t* dst = const_cast<uint16_t*>(which == 0 ? d.a : d.b);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int sline = row + 32 * i;
+        if (EDGE && s0 + sline >= S) continue;
+        const uint4 v = cur[i];
+        const unsigned w4[4] = {v.x, v.y, v.z, v.w};
+        uint4 o;
+        unsigned r4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          r4[q] = ff_corrected_by<FF>(w4[q] & 0xffffu, fr[8 * i + 2 * q], vmax) |
+                  (ff_corrected_by<FF>(w4[q] >> 16, fr[8 * i + 2 * q + 1], vmax) << 16);
+        o.x = r4[0];
+        o.y = r4[1];
+        o.z = r4[2];
+        o.w = r4[3];
+        *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + sline) * W + l0 + 8 * sub) = o;
+      }
+      cur[0] = nxt[0];
+      cur[1] = nxt[1];
+      p = pn;
     }
   }
 }
@@ -4748,10 +4830,10 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
       const bool tiled = vec_top && H % 64 == 0 && W % 64 == 0;
       const bool fast = tiled && w_left % 64 == 0 && w_top % 64 == 0;
       if (tiled) {
-        const dim3 grid(std::max(H, W) / 64, (std::max(w_left, w_top) + 63) / 64, 2 * n);
+        const dim3 grid(std::max(H, W) / 64, (std::max(w_left, w_top) + 63) / 64, 4 * ((n + kStagePairs - 1) / kStagePairs));
 #define MS_STAGE(FF, EDGE)                                                                                           \
   MS_LAUNCH(ctx, "k_stage_strips", (k_stage_strips64<FF, EDGE>), grid, dim3(256), 0, tiles, tile_pitch, H, W, w_left, \
-            w_top, pair_idx, ws.desc, status, pair0, ff, (unsigned)ctx->pixel_max)
+            w_top, pair_idx, ws.desc, status, pair0, n, ff, (unsigned)ctx->pixel_max)
         if (ff_type == MISTITCH_FF_F32) {
           if (fast) MS_STAGE(MISTITCH_FF_F32, false);
           else MS_STAGE(MISTITCH_FF_F32, true);
