@@ -164,9 +164,36 @@ constexpr int kBinRows = 8;
 __global__ __launch_bounds__(256) void k_fuse_bins(int n_tiles, int H, int W, const int32_t* __restrict__ tile_yx,
                                                    const int32_t* __restrict__ tile_plane, int32_t* __restrict__ bins,
                                                    int gx, int gy, int n_planes, int Wm, int row0, int row1, int kBW,
-                                                   int32_t* ff_verdict) {
+                                                   const int32_t* __restrict__ tile_ff, int32_t* ff_verdict) {
   const int lane = threadIdx.x & 63;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *ff_verdict = 1;  // k_ff_check, next on the stream, may clear it
+  if (blockIdx.x == 0) {
+    // For k_ff_check, next on the stream: ff_verdict[0] = 1 (it may clear it; a flatfield plane index beyond
+    // kFfPlanes clears it here), ff_verdict[1..2] = which of the planes 0..63 some tile uses, one bit each.
+    __shared__ unsigned part[4][3];
+    unsigned lo = 0, hi = 0, beyond = 0;
+    for (int t = threadIdx.x; tile_ff && t < n_tiles; t += blockDim.x) {
+      const int f = tile_ff[t];  // negative: the tile has no plane
+      lo |= f >= 0 && f < 32 ? 1u << f : 0u;
+      hi |= f >= 32 && f < 64 ? 1u << (f - 32) : 0u;
+      beyond |= f >= 64;
+    }
+    for (int s = 1; s < 64; s <<= 1) {
+      lo |= __shfl_xor(lo, s);
+      hi |= __shfl_xor(hi, s);
+      beyond |= __shfl_xor(beyond, s);
+    }
+    if (lane == 0) {
+      part[threadIdx.x >> 6][0] = lo;
+      part[threadIdx.x >> 6][1] = hi;
+      part[threadIdx.x >> 6][2] = beyond;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      ff_verdict[0] = (part[0][2] | part[1][2] | part[2][2] | part[3][2]) ? 0 : 1;
+      ff_verdict[1] = (int32_t)(part[0][0] | part[1][0] | part[2][0] | part[3][0]);
+      ff_verdict[2] = (int32_t)(part[0][1] | part[1][1] | part[2][1] | part[3][1]);
+    }
+  }
   const int gyg = (gy + kBinRows - 1) / kBinRows;
   const int64_t grp = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (grp >= (int64_t)gx * gyg * n_planes) return;
@@ -827,37 +854,36 @@ __global__ __launch_bounds__(kFuseThreads) void k_fuse(const uint16_t* __restric
 }
 
 // Are all float32 flatfield values that this call uses finite and within [2^-16, 2^16]?
-// grid (kFfChunks, kFfPlanes): block (c, p) looks whether any tile uses plane p and, if
-// so, scans chunk c of it; a violation (or a plane index >= kFfPlanes) clears *verdict,
-// which has been set nonzero before (k_fuse_bins, or a memset).
+// grid (kFfChunks, kFfPlanes): block (c, p) scans chunk c of plane p if a tile uses the plane
+// (`many_planes`: bit p of verdict[1..2], written by k_fuse_bins before; else the single plane 0);
+// a violation clears verdict[0], which has been set before (k_fuse_bins, or a memset).
 constexpr int kFfChunks = 512, kFfPlanes = 64;
-__global__ __launch_bounds__(256) void k_ff_check(const float* __restrict__ flatfields,
-                                                  const int32_t* __restrict__ tile_ff, int n_tiles, int64_t plane_px,
-                                                  int32_t* verdict) {
+static_assert(kFfPlanes == 64, "k_fuse_bins keeps one bit per plane in two 32-bit words");
+__global__ __launch_bounds__(256) void k_ff_check(const float* __restrict__ flatfields, int many_planes,
+                                                  int64_t plane_px, int32_t* verdict) {
   const int p = blockIdx.y;
-  int used = 0, beyond = 0;
-  if (!tile_ff) used = p == 0;  // a single plane
-  for (int t = threadIdx.x; tile_ff && t < n_tiles; t += blockDim.x) {
-    const int f = tile_ff[t];
-    used |= f == p;
-    beyond |= f >= kFfPlanes;
-  }
-  used = __syncthreads_or(used);
-  beyond = __syncthreads_or(beyond);
-  if (beyond && threadIdx.x == 0 && blockIdx.x == 0 && p == 0) *verdict = 0;
-  if (!used) return;
+  if (many_planes ? !(((unsigned)verdict[1 + (p >> 5)] >> (p & 31)) & 1u) : p != 0) return;
   const float* plane = flatfields + (int64_t)p * plane_px;
   const int64_t per = ((plane_px + kFfChunks - 1) / kFfChunks + 3) & ~(int64_t)3;
   const int64_t i0 = per * blockIdx.x, i1 = min(plane_px, i0 + per);
   int bad = 0;
   // positive, exponent within +-16: bits in [0x37800000, 0x47800000]
-  for (int64_t i = i0 + 4 * threadIdx.x; i < i1; i += 4 * blockDim.x) {
+  auto worst_of = [](const F8& q) {  // 4-byte aligned 16-byte read of the first half
+    return max(max(__float_as_uint(q.v[0]) - 0x37800000u, __float_as_uint(q.v[1]) - 0x37800000u),
+               max(__float_as_uint(q.v[2]) - 0x37800000u, __float_as_uint(q.v[3]) - 0x37800000u));
+  };
+  const int64_t stride = 4 * (int64_t)blockDim.x;
+  int64_t i = i0 + 4 * threadIdx.x;
+  for (; i + 3 * stride + 4 <= i1; i += 4 * stride) {  // four reads in flight
+    const unsigned w0 = worst_of(*reinterpret_cast<const F8*>(plane + i));
+    const unsigned w1 = worst_of(*reinterpret_cast<const F8*>(plane + i + stride));
+    const unsigned w2 = worst_of(*reinterpret_cast<const F8*>(plane + i + 2 * stride));
+    const unsigned w3 = worst_of(*reinterpret_cast<const F8*>(plane + i + 3 * stride));
+    bad |= max(max(w0, w1), max(w2, w3)) > 0x10000000u;
+  }
+  for (; i < i1; i += stride) {
     if (i + 4 <= i1) {
-      const F8* q = reinterpret_cast<const F8*>(plane + i);  // 4-byte aligned 16-byte read of the first half
-      const float a = q->v[0], b = q->v[1], c = q->v[2], d = q->v[3];
-      const unsigned worst = max(max(__float_as_uint(a) - 0x37800000u, __float_as_uint(b) - 0x37800000u),
-                                 max(__float_as_uint(c) - 0x37800000u, __float_as_uint(d) - 0x37800000u));
-      bad |= worst > 0x10000000u;
+      bad |= worst_of(*reinterpret_cast<const F8*>(plane + i)) > 0x10000000u;
     } else {
       for (int64_t e = i; e < i1; ++e) bad |= !(__float_as_uint(plane[e]) - 0x37800000u <= 0x10000000u);
     }
@@ -1147,10 +1173,10 @@ static int fuse_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_tiles, int 
   const int64_t n_bin_groups = (int64_t)grid.x * ((grid.y + kBinRows - 1) / kBinRows) * grid.z;
   MS_LAUNCH(ctx, "k_fuse_bins", k_fuse_bins, dim3((unsigned)((n_bin_groups + 3) / 4)), dim3(256), 0, n_tiles, tile_h, tile_w,
             tile_yx, tile_plane, reinterpret_cast<int32_t*>(ws), (int)grid.x, (int)grid.y, n_planes, mosaic_w,
-            row0, row_end, 512 * GX * kWX, ff_safe);
+            row0, row_end, 512 * GX * kWX, ff_type == MISTITCH_FF_F32 ? tile_ff : (const int32_t*)nullptr, ff_safe);
   if (ff_type == MISTITCH_FF_F32 && n_tiles > 0)
     MS_LAUNCH(ctx, "k_ff_check", k_ff_check, dim3(kFfChunks, kFfPlanes), dim3(256), 0,
-              reinterpret_cast<const float*>(flatfields), tile_ff, n_tiles, (int64_t)tile_h * tile_w, ff_safe);
+              reinterpret_cast<const float*>(flatfields), 1, (int64_t)tile_h * tile_w, ff_safe);
   // Lanes of k_fuse without a plain copy still issue their 16-byte pixel load (and 32- or 64-byte flatfield load), at
   // the start of the tile / flatfield array.  An array of fewer than 8 values does not hold such a load: the idle
   // loads then go to the workspace instead (at least 148 bytes, 16-byte aligned), addressed relative to the arrays.
@@ -1230,7 +1256,7 @@ extern "C" int mistitch_apply_flatfield(mistitch_ctx* ctx, const uint16_t* in, c
   if (ff_type == MISTITCH_FF_F32) {
     MS_HIP(hipMemsetAsync(ff_safe, 1, sizeof(int32_t), ctx->stream));
     MS_LAUNCH(ctx, "k_ff_check", k_ff_check, dim3(kFfChunks, 1), dim3(256), 0, reinterpret_cast<const float*>(flatfield),
-              (const int32_t*)nullptr, 0, npx, ff_safe);
+              0, npx, ff_safe);
   }
   const unsigned tiles_per_launch = bpt ? std::max(1u, 0x7fffffffu / bpt) : 1u;
   for (unsigned t0 = 0; gpt && t0 < (unsigned)n_tiles; t0 += tiles_per_launch) {

@@ -45,6 +45,30 @@ def test_flatfield_fusion_matches_oracle(fu, ffdt, mode):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("mode", ["overwrite", "feather"])
+@pytest.mark.parametrize("case", ["odd_value_in_plane_37", "odd_value_in_an_unused_plane", "planes_beyond_63"])
+def test_flatfield_range_check_over_many_planes(fu, mode, case):
+    """The float32 division is scaling-free only when every value of every USED plane is an ordinary one; which
+    planes are used is worked out on the device from tile_ff (planes 0..63 one by one, any plane beyond them
+    switches to the full division).  Whatever path is taken, results equal the oracle's."""
+    tiles, yx, plane, mh, mw = overlapping_scene(77, 3, 3, 40, 72, n_planes=1)
+    n_ff = 72 if case == "planes_beyond_63" else 40
+    ffs = np.stack([synth.make_flatfield(40, 72, dtype=np.float32, amplitude=0.05 + 0.01 * (k % 30)) for k in range(n_ff)])
+    tile_ff = np.array([0, 37, 5, -1, 33, 37, 31, 32, 0], dtype=np.int32)
+    if case == "odd_value_in_plane_37":
+        ffs[37, 11, 13], ffs[37, 39, 71], ffs[37, 0, 0] = 1e-30, np.inf, -2.0
+    elif case == "odd_value_in_an_unused_plane":
+        ffs[36, 11, 13], ffs[38, 0, 0], ffs[1, 5, 5] = 1e-30, np.inf, np.nan
+    else:
+        tile_ff[[2, 6]] = [64, 71]
+        ffs[71, 3, 3] = 1e-30
+    oracle = ofu.fuse_overwrite if mode == "overwrite" else ofu.fuse_feather
+    with np.errstate(all="ignore"):
+        ref = oracle(tiles, yx, plane, 1, mh, mw, flatfields=ffs, tile_ff=tile_ff)
+    got = _np(fu.fuse_tiles(tiles, yx, plane, 1, mh, mw, flatfields=ffs, tile_ff=tile_ff, mode=mode))
+    assert np.array_equal(got, ref)
+
+
 def test_feather_matches_oracle_and_properties(fu):
     tiles, yx, plane, mh, mw = overlapping_scene(31, 3, 4, 80, 112, n_planes=1, overlap=0.25)
     ref = ofu.fuse_feather(tiles, yx, plane, 1, mh, mw)
