@@ -3100,10 +3100,33 @@ __device__ __forceinline__ void add_planes(const unsigned (&v)[kPlanes], bool ta
   }
 }
 
-template <bool LA, bool LB>
+// Lane i takes the value of lane i + 1 of the wave (the last lane keeps its own).
+constexpr int kDppWaveShl1 = 0x130;
+__device__ __forceinline__ unsigned from_next_lane(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(v, v, kDppWaveShl1, 0xf, 0xf, false);
+}
+
+// The 8 pixels from an ODD pixel offset on: x holds the four dwords from one pixel before (a 4-byte aligned load: a
+// 16-byte load from an odd 2-byte boundary costs about twice one from a 4-byte boundary), the eighth pixel is the low half of the
+// dword behind them, which is the first dword of the next lane's load, or `own_tail` for a lane with `lonely` set.
+__device__ __forceinline__ void shift_in_odd(U16x8& x, unsigned own_tail, bool lonely) {
+  const unsigned next = from_next_lane(x.d[0]);
+  const unsigned d4 = lonely ? own_tail : next;
+  x.d[0] = __builtin_amdgcn_alignbit(x.d[1], x.d[0], 16);
+  x.d[1] = __builtin_amdgcn_alignbit(x.d[2], x.d[1], 16);
+  x.d[2] = __builtin_amdgcn_alignbit(x.d[3], x.d[2], 16);
+  x.d[3] = __builtin_amdgcn_alignbit(d4, x.d[3], 16);
+}
+
+// ODD: both column lags are odd (off_a and off_b of every lane whose sums count are odd; lanes that do not count
+// have offset 0).  lonely_a / lonely_b: the lane after this one does not load the pixels that follow this lane's.
+template <bool LA, bool LB, bool ODD>
 __device__ __forceinline__ void sweep_rows(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, int64_t pitch,
-                                           int r0, int r1, int off_a, int off_b, SweepAcc& acc) {
+                                           int r0, int r1, int off_a, int off_b, bool lonely_a, bool lonely_b,
+                                           SweepAcc& acc) {
   // a, b: the lane's group in row 0 of the first strip / the start of the paired row of the second
+  const int ld_a = ODD ? max(off_a - 1, 0) : off_a, ld_b = ODD ? max(off_b - 1, 0) : off_b;
+  const bool lonely = ODD && ((LA && lonely_a) || (LB && lonely_b));
   int r = r0;
 #pragma unroll 1
   for (; r + 1 < r1; r += 2) {  // two rows per trip: six 16-byte loads in flight per lane
@@ -3117,12 +3140,21 @@ __device__ __forceinline__ void sweep_rows(const uint16_t* __restrict__ a, const
     (void)br;
 #else
     if constexpr (LA) {
-      xa0 = *reinterpret_cast<const U16x8*>(br + off_a);
-      xa1 = *reinterpret_cast<const U16x8*>(br + pitch + off_a);
+      xa0 = *reinterpret_cast<const U16x8*>(br + ld_a);
+      xa1 = *reinterpret_cast<const U16x8*>(br + pitch + ld_a);
     }
     if constexpr (LB) {
-      xb0 = *reinterpret_cast<const U16x8*>(br + off_b);
-      xb1 = *reinterpret_cast<const U16x8*>(br + pitch + off_b);
+      xb0 = *reinterpret_cast<const U16x8*>(br + ld_b);
+      xb1 = *reinterpret_cast<const U16x8*>(br + pitch + ld_b);
+    }
+    if constexpr (ODD) {
+      unsigned ta0 = 0, ta1 = 0, tb0 = 0, tb1 = 0;
+      if (lonely) {  // few lanes: the last of a wave, the one before the group that the wrap column cuts
+        if constexpr (LA) ta0 = br[off_a + 7], ta1 = br[pitch + off_a + 7];
+        if constexpr (LB) tb0 = br[off_b + 7], tb1 = br[pitch + off_b + 7];
+      }
+      if constexpr (LA) shift_in_odd(xa0, ta0, lonely_a), shift_in_odd(xa1, ta1, lonely_a);
+      if constexpr (LB) shift_in_odd(xb0, tb0, lonely_b), shift_in_odd(xb1, tb1, lonely_b);
     }
 #endif
 #if defined(MS_SWEEP_ABLATE) && MS_SWEEP_ABLATE == 2  /* measurement build: loads only */
@@ -3141,8 +3173,17 @@ __device__ __forceinline__ void sweep_rows(const uint16_t* __restrict__ a, const
     const uint16_t* br = b + (int64_t)r * pitch;
     const U16x8 va0 = *reinterpret_cast<const U16x8*>(ar);
     U16x8 xa0{}, xb0{};
-    if constexpr (LA) xa0 = *reinterpret_cast<const U16x8*>(br + off_a);
-    if constexpr (LB) xb0 = *reinterpret_cast<const U16x8*>(br + off_b);
+    if constexpr (LA) xa0 = *reinterpret_cast<const U16x8*>(br + ld_a);
+    if constexpr (LB) xb0 = *reinterpret_cast<const U16x8*>(br + ld_b);
+    if constexpr (ODD) {
+      unsigned ta0 = 0, tb0 = 0;
+      if (lonely) {
+        if constexpr (LA) ta0 = br[off_a + 7];
+        if constexpr (LB) tb0 = br[off_b + 7];
+      }
+      if constexpr (LA) shift_in_odd(xa0, ta0, lonely_a);
+      if constexpr (LB) shift_in_odd(xb0, tb0, lonely_b);
+    }
     acc.add4<LA, LB>(va0.d[0], va0.d[1], xa0.d[0], xa0.d[1], xb0.d[0], xb0.d[1]);
     acc.add4<LA, LB>(va0.d[2], va0.d[3], xa0.d[2], xa0.d[3], xb0.d[2], xb0.d[3]);
   }
@@ -3256,15 +3297,25 @@ __global__ __launch_bounds__(kThreads, MS_SWEEP_OCC) void k_ncc_sweep(const Pair
     side_b = c + m >= L ? 1 : 0;
     off_b = c + m >= L ? c + m - L : c + m;
   }
+  // odd lags (m odd: both at once): a lane's 16-byte loads start one pixel early, on a 4-byte boundary, and its last
+  // pixel comes from the lane after it, unless that lane loads something else
+  const bool odd = (m & 1) != 0;
+  auto lonely_at = [&](int cut) {
+    return (tid & 63) == 63 || gidx + 1 >= ngroups || gidx + 1 == cut;
+  };
+  const bool lonely_a = lonely_at(cut_a), lonely_b = lonely_at(cut_b);
   SweepAcc sa;
   const uint16_t* a_lane = d.a + c;
   const uint16_t* b_rows = d.b + (int64_t)(-ds) * d.pitch;  // row r of the first strip meets row r - ds of the second
-  if (lag_a && lag_b)
-    sweep_rows<true, true>(a_lane, b_rows, d.pitch, r0, r1, off_a, off_b, sa);
-  else if (lag_a)
-    sweep_rows<true, false>(a_lane, b_rows, d.pitch, r0, r1, off_a, off_b, sa);
-  else
-    sweep_rows<false, true>(a_lane, b_rows, d.pitch, r0, r1, off_a, off_b, sa);
+#define MS_SWEEP(LA, LB)                                                                                  \
+  do {                                                                                                    \
+    if (odd) sweep_rows<LA, LB, true>(a_lane, b_rows, d.pitch, r0, r1, off_a, off_b, lonely_a, lonely_b, sa); \
+    else sweep_rows<LA, LB, false>(a_lane, b_rows, d.pitch, r0, r1, off_a, off_b, false, false, sa);      \
+  } while (0)
+  if (lag_a && lag_b) MS_SWEEP(true, true);
+  else if (lag_a) MS_SWEEP(true, false);
+  else MS_SWEEP(false, true);
+#undef MS_SWEEP
   __syncthreads();  // red is zero
 #pragma unroll
   for (int lag = 0; lag < 2; ++lag) {
