@@ -3026,25 +3026,26 @@ __global__ __launch_bounds__(kThreads, 8) void k_ncc_accumulate(const PairDesc* 
 // the second: the rows r >= n belong to the former, the rows r < n to the latter, and together they are every row
 // once.  The same holds along a row for +m and -(L - m), and for the opposite lags.  So four circular sweeps of the
 // strip pair (row lag +-n, column lag +-m) visit every pixel pair of all 16 overlaps exactly once, where 16 separate
-// windows read four strip areas of either strip.  A workgroup takes up to kSweepRows rows of one row lag on one side of
-// the wrap, loads a row of the first strip ONCE (16 bytes per lane, aligned) and the paired row of the second strip at
-// the two column lags, and keeps the byte-plane sums of both lags: the moments of the first strip are formed once, not
+// windows read four strip areas of either strip.  A workgroup takes up to kSweepRows rows that lie on one side of the
+// wrap row of EITHER row lag, loads a row of the first strip ONCE (16 bytes per lane, aligned) and its partner rows of
+// both row lags at the two column lags (four loads, on 4-byte boundaries; a row lag whose candidates are all ruled out
+// is left out), and keeps the byte-plane sums of all four: the moments of the first strip are formed once, not
 // once per candidate.  Every lane owns one 8-pixel group of the row, which lies on one side of a lag's wrap column for
-// all rows, so its sums go to one candidate per lag.  The one group that a lag's wrap column cuts is left out of that
-// lag's sums and taken pixel by pixel afterwards, wave w for (lag w / 2, side w % 2).
+// all rows, so its sums go to one candidate per row lag and column lag.  The one group that a column lag's wrap column
+// cuts is left out of that lag's sums and taken pixel by pixel afterwards, wave w for (lag w / 2, side w % 2).
 // Byte-plane sums are reduced over the 16 lanes of a DPP row in 32 bits and added to the workgroup's 64-bit planes in
-// LDS; 20 threads turn the planes into moments and add them to the candidates' accumulators.
-// grid: 8 * ceil(pairs_in_pass / 8) * n_peaks * 2 * n_row_chunks * n_col_chunks workgroups, a pair's on one XCD as in
+// LDS; 40 threads turn the planes into moments and add them to the candidates' accumulators.
+// grid: 8 * ceil(pairs_in_pass / 8) * n_peaks * n_row_chunks * n_col_chunks workgroups, a pair's on one XCD as in
 // k_ncc_accumulate.  Rows are 16-byte aligned and L is a multiple of 8 (the host checks).
 #ifndef MS_SWEEP_ROWS
-#define MS_SWEEP_ROWS 32
+#define MS_SWEEP_ROWS 64
 #endif
 #ifndef MS_SWEEP_OCC
-#define MS_SWEEP_OCC 6
+#define MS_SWEEP_OCC 5
 #endif
 constexpr int kSweepRows = MS_SWEEP_ROWS;
-// a lane calls add4 twice per row; the busiest byte plane gains at most 520,200 per call, and the sum of a plane over
-// the 16 lanes of a DPP row has to fit 32 bits (row_sum)
+// a lane adds four pixels to a stream twice per row; the busiest byte plane gains at most 520,200 each time, and the
+// sum of a plane over the 16 lanes of a DPP row has to fit 32 bits (row_sum)
 static_assert(2ll * kSweepRows * 520200ll * 16ll < (1ll << 32), "byte-plane sums of 16 lanes overflow 32 bits");
 constexpr int kPlanes = 13;  // a_l a_h b_l b_h aa_ll aa_lh aa_hh bb_ll bb_lh bb_hh ab_ll ab_x ab_hh
 
@@ -3057,32 +3058,42 @@ __device__ __forceinline__ unsigned row_sum(unsigned v) {
   return v;
 }
 
+// NB second-strip streams against one first-strip stream (2: the column lags of one row lag; 4: of both row lags,
+// stream 2 * row lag + column lag).
+template <int NB>
 struct SweepAcc {
-  unsigned a_l = 0, a_h = 0, aa_ll = 0, aa_lh = 0, aa_hh = 0;  // first strip: shared by both lags
-  unsigned b_l[2] = {0, 0}, b_h[2] = {0, 0}, bb_ll[2] = {0, 0}, bb_lh[2] = {0, 0}, bb_hh[2] = {0, 0};
-  unsigned ab_ll[2] = {0, 0}, ab_x[2] = {0, 0}, ab_hh[2] = {0, 0};
-  template <bool LA, bool LB>
-  __device__ __forceinline__ void add4(unsigned a0, unsigned a1, unsigned x0, unsigned x1, unsigned y0, unsigned y1) {
-    const unsigned al = __builtin_amdgcn_perm(a1, a0, 0x06040200u), ah = __builtin_amdgcn_perm(a1, a0, 0x07050301u);
+  unsigned a_l = 0, a_h = 0, aa_ll = 0, aa_lh = 0, aa_hh = 0;  // first strip: shared by all streams
+  unsigned b_l[NB] = {}, b_h[NB] = {}, bb_ll[NB] = {}, bb_lh[NB] = {}, bb_hh[NB] = {};
+  unsigned ab_ll[NB] = {}, ab_x[NB] = {}, ab_hh[NB] = {};
+  // four pixels of the first strip: their own sums; al, ah = their low and high bytes
+  __device__ __forceinline__ void first(unsigned a0, unsigned a1, unsigned& al, unsigned& ah) {
+    al = __builtin_amdgcn_perm(a1, a0, 0x06040200u), ah = __builtin_amdgcn_perm(a1, a0, 0x07050301u);
     a_l = __builtin_amdgcn_udot4(al, 0x01010101u, a_l, false);
     a_h = __builtin_amdgcn_udot4(ah, 0x01010101u, a_h, false);
     aa_ll = __builtin_amdgcn_udot4(al, al, aa_ll, false);
     aa_lh = __builtin_amdgcn_udot4(al, ah, aa_lh, false);
     aa_hh = __builtin_amdgcn_udot4(ah, ah, aa_hh, false);
-    auto lag = [&](int k, unsigned b0, unsigned b1) {
-      const unsigned bl = __builtin_amdgcn_perm(b1, b0, 0x06040200u), bh = __builtin_amdgcn_perm(b1, b0, 0x07050301u);
-      b_l[k] = __builtin_amdgcn_udot4(bl, 0x01010101u, b_l[k], false);
-      b_h[k] = __builtin_amdgcn_udot4(bh, 0x01010101u, b_h[k], false);
-      bb_ll[k] = __builtin_amdgcn_udot4(bl, bl, bb_ll[k], false);
-      bb_lh[k] = __builtin_amdgcn_udot4(bl, bh, bb_lh[k], false);
-      bb_hh[k] = __builtin_amdgcn_udot4(bh, bh, bb_hh[k], false);
-      ab_ll[k] = __builtin_amdgcn_udot4(al, bl, ab_ll[k], false);
-      ab_x[k] = __builtin_amdgcn_udot4(al, bh, ab_x[k], false);
-      ab_x[k] = __builtin_amdgcn_udot4(ah, bl, ab_x[k], false);
-      ab_hh[k] = __builtin_amdgcn_udot4(ah, bh, ab_hh[k], false);
-    };
-    if constexpr (LA) lag(0, x0, x1);
-    if constexpr (LB) lag(1, y0, y1);
+  }
+  // the four pixels that stream k pairs with them
+  __device__ __forceinline__ void second(int k, unsigned al, unsigned ah, unsigned b0, unsigned b1) {
+    const unsigned bl = __builtin_amdgcn_perm(b1, b0, 0x06040200u), bh = __builtin_amdgcn_perm(b1, b0, 0x07050301u);
+    b_l[k] = __builtin_amdgcn_udot4(bl, 0x01010101u, b_l[k], false);
+    b_h[k] = __builtin_amdgcn_udot4(bh, 0x01010101u, b_h[k], false);
+    bb_ll[k] = __builtin_amdgcn_udot4(bl, bl, bb_ll[k], false);
+    bb_lh[k] = __builtin_amdgcn_udot4(bl, bh, bb_lh[k], false);
+    bb_hh[k] = __builtin_amdgcn_udot4(bh, bh, bb_hh[k], false);
+    ab_ll[k] = __builtin_amdgcn_udot4(al, bl, ab_ll[k], false);
+    ab_x[k] = __builtin_amdgcn_udot4(al, bh, ab_x[k], false);
+    ab_x[k] = __builtin_amdgcn_udot4(ah, bl, ab_x[k], false);
+    ab_hh[k] = __builtin_amdgcn_udot4(ah, bh, ab_hh[k], false);
+  }
+  // streams K0 (if LA) and K0 + 1 (if LB)
+  template <bool LA, bool LB, int K0 = 0>
+  __device__ __forceinline__ void add4(unsigned a0, unsigned a1, unsigned x0, unsigned x1, unsigned y0, unsigned y1) {
+    unsigned al, ah;
+    first(a0, a1, al, ah);
+    if constexpr (LA) second(K0, al, ah, x0, x1);
+    if constexpr (LB) second(K0 + 1, al, ah, y0, y1);
   }
   __device__ __forceinline__ void planes(int k, unsigned (&v)[kPlanes]) const {
     v[0] = a_l, v[1] = a_h, v[2] = b_l[k], v[3] = b_h[k], v[4] = aa_ll, v[5] = aa_lh, v[6] = aa_hh;
@@ -3120,10 +3131,10 @@ __device__ __forceinline__ void shift_in_odd(U16x8& x, unsigned own_tail, bool l
 
 // ODD: both column lags are odd (off_a and off_b of every lane whose sums count are odd; lanes that do not count
 // have offset 0).  lonely_a / lonely_b: the lane after this one does not load the pixels that follow this lane's.
-template <bool LA, bool LB, bool ODD>
+template <bool LA, bool LB, bool ODD, int K0>
 __device__ __forceinline__ void sweep_rows(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, int64_t pitch,
                                            int r0, int r1, int off_a, int off_b, bool lonely_a, bool lonely_b,
-                                           SweepAcc& acc) {
+                                           SweepAcc<4>& acc) {
   // a, b: the lane's group in row 0 of the first strip / the start of the paired row of the second
   const int ld_a = ODD ? max(off_a - 1, 0) : off_a, ld_b = ODD ? max(off_b - 1, 0) : off_b;
   const bool lonely = ODD && ((LA && lonely_a) || (LB && lonely_b));
@@ -3162,10 +3173,10 @@ __device__ __forceinline__ void sweep_rows(const uint16_t* __restrict__ a, const
                xa0.d[2] ^ xa0.d[3] ^ xb0.d[0] ^ xb0.d[1] ^ xb0.d[2] ^ xb0.d[3] ^ xa1.d[0] ^ xa1.d[1] ^ xa1.d[2] ^ xa1.d[3] ^
                xb1.d[0] ^ xb1.d[1] ^ xb1.d[2] ^ xb1.d[3];
 #else
-    acc.add4<LA, LB>(va0.d[0], va0.d[1], xa0.d[0], xa0.d[1], xb0.d[0], xb0.d[1]);
-    acc.add4<LA, LB>(va0.d[2], va0.d[3], xa0.d[2], xa0.d[3], xb0.d[2], xb0.d[3]);
-    acc.add4<LA, LB>(va1.d[0], va1.d[1], xa1.d[0], xa1.d[1], xb1.d[0], xb1.d[1]);
-    acc.add4<LA, LB>(va1.d[2], va1.d[3], xa1.d[2], xa1.d[3], xb1.d[2], xb1.d[3]);
+    acc.add4<LA, LB, K0>(va0.d[0], va0.d[1], xa0.d[0], xa0.d[1], xb0.d[0], xb0.d[1]);
+    acc.add4<LA, LB, K0>(va0.d[2], va0.d[3], xa0.d[2], xa0.d[3], xb0.d[2], xb0.d[3]);
+    acc.add4<LA, LB, K0>(va1.d[0], va1.d[1], xa1.d[0], xa1.d[1], xb1.d[0], xb1.d[1]);
+    acc.add4<LA, LB, K0>(va1.d[2], va1.d[3], xa1.d[2], xa1.d[3], xb1.d[2], xb1.d[3]);
 #endif
   }
   if (r < r1) {
@@ -3184,8 +3195,56 @@ __device__ __forceinline__ void sweep_rows(const uint16_t* __restrict__ a, const
       if constexpr (LA) shift_in_odd(xa0, ta0, lonely_a);
       if constexpr (LB) shift_in_odd(xb0, tb0, lonely_b);
     }
-    acc.add4<LA, LB>(va0.d[0], va0.d[1], xa0.d[0], xa0.d[1], xb0.d[0], xb0.d[1]);
-    acc.add4<LA, LB>(va0.d[2], va0.d[3], xa0.d[2], xa0.d[3], xb0.d[2], xb0.d[3]);
+    acc.add4<LA, LB, K0>(va0.d[0], va0.d[1], xa0.d[0], xa0.d[1], xb0.d[0], xb0.d[1]);
+    acc.add4<LA, LB, K0>(va0.d[2], va0.d[3], xa0.d[2], xa0.d[3], xb0.d[2], xb0.d[3]);
+  }
+}
+
+// Both row lags at once: row r of the first strip is loaded once and meets its partner rows of both lags (b0: lag +n,
+// b1: lag -n), each at the two column lags.  One row per trip: five 16-byte loads in flight per lane.
+template <bool LA, bool LB, bool ODD>
+__device__ __forceinline__ void sweep_rows_both(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b0,
+                                                const uint16_t* __restrict__ b1, int64_t pitch, int r0, int r1, int off_a,
+                                                int off_b, bool lonely_a, bool lonely_b, SweepAcc<4>& acc) {
+  const int ld_a = ODD ? max(off_a - 1, 0) : off_a, ld_b = ODD ? max(off_b - 1, 0) : off_b;
+  const bool lonely = ODD && ((LA && lonely_a) || (LB && lonely_b));
+#pragma unroll 1
+  for (int r = r0; r < r1; ++r) {
+    const uint16_t* ar = a + (int64_t)r * pitch;
+    const uint16_t* br0 = b0 + (int64_t)r * pitch;
+    const uint16_t* br1 = b1 + (int64_t)r * pitch;
+    const U16x8 va = *reinterpret_cast<const U16x8*>(ar);
+    U16x8 xa0{}, xb0{}, xa1{}, xb1{};
+    if constexpr (LA) {
+      xa0 = *reinterpret_cast<const U16x8*>(br0 + ld_a);
+      xa1 = *reinterpret_cast<const U16x8*>(br1 + ld_a);
+    }
+    if constexpr (LB) {
+      xb0 = *reinterpret_cast<const U16x8*>(br0 + ld_b);
+      xb1 = *reinterpret_cast<const U16x8*>(br1 + ld_b);
+    }
+    if constexpr (ODD) {
+      unsigned ta0 = 0, ta1 = 0, tb0 = 0, tb1 = 0;
+      if (lonely) {
+        if constexpr (LA) ta0 = br0[off_a + 7], ta1 = br1[off_a + 7];
+        if constexpr (LB) tb0 = br0[off_b + 7], tb1 = br1[off_b + 7];
+      }
+      if constexpr (LA) shift_in_odd(xa0, ta0, lonely_a), shift_in_odd(xa1, ta1, lonely_a);
+      if constexpr (LB) shift_in_odd(xb0, tb0, lonely_b), shift_in_odd(xb1, tb1, lonely_b);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      unsigned al, ah;
+      acc.first(va.d[2 * h], va.d[2 * h + 1], al, ah);
+      if constexpr (LA) {
+        acc.second(0, al, ah, xa0.d[2 * h], xa0.d[2 * h + 1]);
+        acc.second(2, al, ah, xa1.d[2 * h], xa1.d[2 * h + 1]);
+      }
+      if constexpr (LB) {
+        acc.second(1, al, ah, xb0.d[2 * h], xb0.d[2 * h + 1]);
+        acc.second(3, al, ah, xb1.d[2 * h], xb1.d[2 * h + 1]);
+      }
+    }
   }
 }
 
@@ -3193,20 +3252,18 @@ __global__ __launch_bounds__(kThreads, MS_SWEEP_OCC) void k_ncc_sweep(const Pair
                                                                       int n_in_pass, const Peak* peaks, const Cand* cand,
                                                                       unsigned long long* acc, int n_cand, int n_peaks,
                                                                       int n_row_chunks, int n_col_chunks) {
-  __shared__ unsigned long long red[4][kPlanes + 1];  // [2 * lag + side of the wrap column][byte plane]
+  __shared__ unsigned long long red[8][kPlanes + 1];  // [4 * row lag + 2 * column lag + side of the wrap column][byte plane]
   __shared__ unsigned long long red2[5 * kThreads / 64];
   const int tid = threadIdx.x;
   const int xcd = blockIdx.x % kXcds, seq = blockIdx.x / kXcds;
-  const int per_pair = n_peaks * 2 * n_row_chunks * n_col_chunks;
+  const int per_pair = n_peaks * n_row_chunks * n_col_chunks;
   const int pz = xcd + kXcds * (seq / per_pair);
   if (pz >= n_in_pass) return;
-  // a pair's workgroups in row order: the sweeps of all peaks and both row lags over the same rows of the first strip
-  // are neighbours in the grid and read those rows from L2 at about the same time
+  // a pair's workgroups in row order: the sweeps of all peaks over the same rows of the first strip are neighbours in
+  // the grid and read those rows from L2 at about the same time
   int within = seq % per_pair;
   const int cc = within % n_col_chunks;
   within /= n_col_chunks;
-  const int sig = within & 1;
-  within >>= 1;
   const int pk = within % n_peaks, ch = within / n_peaks;
   const int p = pair0 + pz;
   const int8_t st = status[p];
@@ -3216,50 +3273,53 @@ __global__ __launch_bounds__(kThreads, MS_SWEEP_OCC) void k_ncc_sweep(const Pair
   const int py = peak.key / d.img_w, px = peak.key - py * d.img_w;
   const int n = d.transposed ? px : py, m = d.transposed ? py : px;  // canonical rows, columns: 0 <= n < S, 0 <= m < L
   const int S = d.S, L = d.L;
-  // rows: lag +n pairs row r with row r - n (r >= n: shift +n) or r - n + S (r < n: shift -(S - n)); lag -n pairs it
-  // with r + n (r < S - n: shift -n) or r + n - S (shift +(S - n))
-  // Row chunks: the fixed blocks [j R, (j + 1) R) of the strip, the one that holds the wrap row cut in two there, in row
-  // order (chunk ch of every sweep covers block ch or ch - 1).
-  const int wrap_row = sig ? S - n : n;
-  const int jw = wrap_row / kSweepRows;
-  const bool cut_block = wrap_row % kSweepRows != 0;
-  int r0, r1;
-  bool below;
-  if (!cut_block || ch < jw) {
-    r0 = ch * kSweepRows;
-    r1 = min(r0 + kSweepRows, S);
-    below = r0 < wrap_row;
-  } else if (ch == jw) {
-    r0 = jw * kSweepRows;
-    r1 = wrap_row;
-    below = true;
-  } else {
-    r0 = max((ch - 1) * kSweepRows, wrap_row);
-    r1 = min(ch * kSweepRows, S);
-    below = false;
-  }
+  // rows: lag +n (sig 0) pairs row r with row r - n (r >= n: shift +n) or r - n + S (r < n: shift -(S - n)); lag -n
+  // (sig 1) pairs it with r + n (r < S - n: shift -n) or r + n - S (shift +(S - n)).  Their wrap rows are n and S - n.
+  // Row chunks: the fixed blocks [j R, (j + 1) R) of the strip, cut at both wrap rows, in row order: every chunk lies
+  // on one side of either wrap row.  boundary(i): the i-th smallest of the block starts and the wrap rows.
+  const int w1 = min(n, S - n), w2 = max(n, S - n);
+  const bool e1 = w1 % kSweepRows != 0, e2 = w2 % kSweepRows != 0 && w2 != w1;
+  auto boundary = [&](int i) {
+    if (e2) {
+      const int i2 = w2 / kSweepRows + 1 + (e1 ? 1 : 0);
+      if (i == i2) return w2;
+      if (i > i2) --i;
+    }
+    if (e1) {
+      const int i1 = w1 / kSweepRows + 1;
+      if (i == i1) return w1;
+      if (i > i1) --i;
+    }
+    return min(i * kSweepRows, S);
+  };
+  const int r0 = boundary(ch), r1 = boundary(ch + 1);
   if (r0 >= r1) return;
-  const int row_mag = (sig != 0) != below ? 1 : 0;  // 0: magnitude n, 1: S - n
-  const int row_pos = below ? 0 : 1;                // sign of the row shift
-  const int ds = (row_pos ? 1 : -1) * (row_mag ? S - n : n);
-  // the four candidates of this workgroup, q = 2 * lag + side: lag 0 reads the second strip at column (c - m) mod L
-  // (side 1, c >= m: shift +m; side 0: shift -(L - m)), lag 1 at (c + m) mod L (side 0, c < L - m: shift -m; side 1:
-  // shift +(L - m))
+  // the eight candidates of this workgroup, 4 * sig + q with q = 2 * lag + side: lag 0 reads the second strip at column
+  // (c - m) mod L (side 1, c >= m: shift +m; side 0: shift -(L - m)), lag 1 at (c + m) mod L (side 0, c < L - m:
+  // shift -m; side 1: shift +(L - m))
   const int slots = n_cand + 1;
-  int ci[4], dl[4];
-  bool live[4];
+  int ci[8], dl[4], ds[2];
+  bool live[8];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int lag = q >> 1, side = q & 1;
-    const int col_mag = lag ? side : 1 - side;
-    const int col_pos = side;
-    dl[q] = (col_pos ? 1 : -1) * (col_mag ? L - m : m);
-    const int t = d.transposed ? (col_mag << 3) | (row_mag << 2) | (col_pos << 1) | row_pos
-                               : (row_mag << 3) | (col_mag << 2) | (row_pos << 1) | col_pos;
-    ci[q] = 16 * pk + t;
-    live[q] = cand[(int64_t)p * slots + ci[q]].flag == 0;
+  for (int sig = 0; sig < 2; ++sig) {
+    const bool below = r0 < (sig ? S - n : n);
+    const int row_mag = (sig != 0) != below ? 1 : 0;  // 0: magnitude n, 1: S - n
+    const int row_pos = below ? 0 : 1;                // sign of the row shift
+    ds[sig] = (row_pos ? 1 : -1) * (row_mag ? S - n : n);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int lag = q >> 1, side = q & 1;
+      const int col_mag = lag ? side : 1 - side;
+      const int col_pos = side;
+      dl[q] = (col_pos ? 1 : -1) * (col_mag ? L - m : m);
+      const int t = d.transposed ? (col_mag << 3) | (row_mag << 2) | (col_pos << 1) | row_pos
+                                 : (row_mag << 3) | (col_mag << 2) | (row_pos << 1) | col_pos;
+      ci[4 * sig + q] = 16 * pk + t;
+      live[4 * sig + q] = cand[(int64_t)p * slots + ci[4 * sig + q]].flag == 0;
+    }
   }
-  const bool lag_a = live[0] | live[1], lag_b = live[2] | live[3];
+  const bool sig_live[2] = {live[0] || live[1] || live[2] || live[3], live[4] || live[5] || live[6] || live[7]};
+  const bool lag_a = live[0] | live[1] | live[4] | live[5], lag_b = live[2] | live[3] | live[6] | live[7];
   if (!(lag_a | lag_b)) return;
   const int ngroups = L >> 3;
   const int g0 = cc * kThreads;  // first group of this column chunk
@@ -3267,23 +3327,25 @@ __global__ __launch_bounds__(kThreads, MS_SWEEP_OCC) void k_ncc_sweep(const Pair
   int cut_a = (lag_a && (m & 7)) ? (m >> 3) : -1;
   int cut_b = (lag_b && ((L - m) & 7)) ? ((L - m) >> 3) : -1;
   if (cut_a >= 0 && cut_a == cut_b) {
-    // both wrap columns cut the same group (m within 8 of L / 2): the four overlaps one by one, windowed as
+    // both wrap columns cut the same group (m within 8 of L / 2): the overlaps one by one, windowed as
     // k_ncc_accumulate does, by the workgroups of the first column chunk
     if (cc != 0) return;
 #pragma unroll 1
-    for (int q = 0; q < 4; ++q) {
-      if (!live[q]) continue;  // uniform
+    for (int e = 0; e < 8; ++e) {
+      if (!live[e]) continue;  // uniform
+      const int q = e & 3, row_shift = ds[e >> 2];
       const int l_lo = dl[q] > 0 ? dl[q] : 0, l_hi = L + (dl[q] < 0 ? dl[q] : 0);
       unsigned long long v[5];
-      moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-ds) * d.pitch + (l_lo - dl[q]), d.pitch, r0, r1, 1, l_hi - l_lo, v);
+      moments_of_rows(d.a + l_lo, d.pitch, d.b + (int64_t)(-row_shift) * d.pitch + (l_lo - dl[q]), d.pitch, r0, r1, 1,
+                      l_hi - l_lo, v);
       __syncthreads();
-      reduce_moments(v, red2, acc + ((int64_t)p * slots + ci[q]) * 5);
+      reduce_moments(v, red2, acc + ((int64_t)p * slots + ci[e]) * 5);
     }
     return;
   }
   if (cut_a < g0 || cut_a >= g0 + kThreads) cut_a = -1;
   if (cut_b < g0 || cut_b >= g0 + kThreads) cut_b = -1;
-  if (tid < 4 * (kPlanes + 1)) red[tid / (kPlanes + 1)][tid % (kPlanes + 1)] = 0ull;
+  if (tid < 8 * (kPlanes + 1)) red[tid / (kPlanes + 1)][tid % (kPlanes + 1)] = 0ull;
   const int gidx = g0 + tid;
   const bool active = gidx < ngroups;
   const int c = active ? 8 * gidx : 0;
@@ -3304,33 +3366,48 @@ __global__ __launch_bounds__(kThreads, MS_SWEEP_OCC) void k_ncc_sweep(const Pair
     return (tid & 63) == 63 || gidx + 1 >= ngroups || gidx + 1 == cut;
   };
   const bool lonely_a = lonely_at(cut_a), lonely_b = lonely_at(cut_b);
-  SweepAcc sa;
+  SweepAcc<4> sa;
   const uint16_t* a_lane = d.a + c;
-  const uint16_t* b_rows = d.b + (int64_t)(-ds) * d.pitch;  // row r of the first strip meets row r - ds of the second
-#define MS_SWEEP(LA, LB)                                                                                  \
-  do {                                                                                                    \
-    if (odd) sweep_rows<LA, LB, true>(a_lane, b_rows, d.pitch, r0, r1, off_a, off_b, lonely_a, lonely_b, sa); \
-    else sweep_rows<LA, LB, false>(a_lane, b_rows, d.pitch, r0, r1, off_a, off_b, false, false, sa);      \
+  // row r of the first strip meets row r - ds of the second
+  const uint16_t* b_rows[2] = {d.b + (int64_t)(-ds[0]) * d.pitch, d.b + (int64_t)(-ds[1]) * d.pitch};
+#define MS_SWEEP_WITH(LA, LB, ODD)                                                                                     \
+  do {                                                                                                                 \
+    if (sig_live[0] && sig_live[1])                                                                                    \
+      sweep_rows_both<LA, LB, ODD>(a_lane, b_rows[0], b_rows[1], d.pitch, r0, r1, off_a, off_b, lonely_a, lonely_b, sa); \
+    else if (sig_live[0])                                                                                              \
+      sweep_rows<LA, LB, ODD, 0>(a_lane, b_rows[0], d.pitch, r0, r1, off_a, off_b, lonely_a, lonely_b, sa);            \
+    else                                                                                                               \
+      sweep_rows<LA, LB, ODD, 2>(a_lane, b_rows[1], d.pitch, r0, r1, off_a, off_b, lonely_a, lonely_b, sa);            \
+  } while (0)
+#define MS_SWEEP(LA, LB)                 \
+  do {                                   \
+    if (odd) MS_SWEEP_WITH(LA, LB, true); \
+    else MS_SWEEP_WITH(LA, LB, false);   \
   } while (0)
   if (lag_a && lag_b) MS_SWEEP(true, true);
   else if (lag_a) MS_SWEEP(true, false);
   else MS_SWEEP(false, true);
 #undef MS_SWEEP
+#undef MS_SWEEP_WITH
   __syncthreads();  // red is zero
 #pragma unroll
-  for (int lag = 0; lag < 2; ++lag) {
-    if (!(lag ? lag_b : lag_a)) continue;  // uniform
-    const int side = lag ? side_b : side_a;
-    unsigned v[kPlanes];
-    sa.planes(lag, v);
+  for (int sig = 0; sig < 2; ++sig) {
+    if (!sig_live[sig]) continue;  // uniform
 #pragma unroll
-    for (int sd = 0; sd < 2; ++sd) {
-      if (__ballot(side == sd) == 0ull) continue;  // wave-uniform: no lane of this wave on that side
-      add_planes(v, side == sd, red[2 * lag + sd]);
+    for (int lag = 0; lag < 2; ++lag) {
+      if (!(lag ? lag_b : lag_a)) continue;  // uniform
+      const int side = lag ? side_b : side_a;
+      unsigned v[kPlanes];
+      sa.planes(2 * sig + lag, v);
+#pragma unroll
+      for (int sd = 0; sd < 2; ++sd) {
+        if (__ballot(side == sd) == 0ull) continue;  // wave-uniform: no lane of this wave on that side
+        add_planes(v, side == sd, red[4 * sig + 2 * lag + sd]);
+      }
     }
   }
   // the cut groups, pixel by pixel: wave w takes the pixels of lag w / 2 on side w % 2 (before the wrap: side 0 for
-  // either lag), lane l pixel l % 8 of them in rows r0 + l / 8, + 8, ...
+  // either lag), lane l pixel l % 8 of them in rows r0 + l / 8, + 8, ..., for one row lag after the other
   {
     const int w = tid >> 6, lane = tid & 63;
     const int lag = w >> 1, sd = w & 1;
@@ -3344,20 +3421,24 @@ __global__ __launch_bounds__(kThreads, MS_SWEEP_OCC) void k_ncc_sweep(const Pair
       int bc = first + i + shift;
       bc += bc < 0 ? L : 0;
       bc -= bc >= L ? L : 0;
-      MomentAcc ma;
-      if (mine) {
-        for (int r = r0 + (lane >> 3); r < r1; r += 8)
-          ma.add1(d.a[(int64_t)r * d.pitch + first + i], b_rows[(int64_t)r * d.pitch + bc]);
+#pragma unroll 1
+      for (int sig = 0; sig < 2; ++sig) {
+        if (!sig_live[sig]) continue;  // uniform
+        MomentAcc ma;
+        if (mine) {
+          for (int r = r0 + (lane >> 3); r < r1; r += 8)
+            ma.add1(d.a[(int64_t)r * d.pitch + first + i], b_rows[sig][(int64_t)r * d.pitch + bc]);
+        }
+        const unsigned v[kPlanes] = {ma.a_l,   ma.a_h,   ma.b_l,   ma.b_h,   ma.aa_ll, ma.aa_lh, ma.aa_hh,
+                                     ma.bb_ll, ma.bb_lh, ma.bb_hh, ma.ab_ll, ma.ab_x,  ma.ab_hh};
+        add_planes(v, true, red[4 * sig + 2 * lag + sd]);
       }
-      const unsigned v[kPlanes] = {ma.a_l,   ma.a_h,   ma.b_l,   ma.b_h,   ma.aa_ll, ma.aa_lh, ma.aa_hh,
-                                   ma.bb_ll, ma.bb_lh, ma.bb_hh, ma.ab_ll, ma.ab_x,  ma.ab_hh};
-      add_planes(v, true, red[2 * lag + sd]);
     }
   }
   __syncthreads();
-  if (tid < 20) {
-    const int q = tid / 5, i = tid % 5;
-    const unsigned long long* pl = red[q];
+  if (tid < 40) {
+    const int e = tid / 5, i = tid % 5;
+    const unsigned long long* pl = red[e];
     unsigned long long v;
     if (i == 0) v = pl[0] + (pl[1] << 8);
     else if (i == 1) v = pl[2] + (pl[3] << 8);
@@ -3366,10 +3447,10 @@ __global__ __launch_bounds__(kThreads, MS_SWEEP_OCC) void k_ncc_sweep(const Pair
     else v = pl[10] + (pl[11] << 8) + (pl[12] << 16);
     bool alive = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) alive = (k == q) ? live[k] : alive;
+    for (int k = 0; k < 8; ++k) alive = (k == e) ? live[k] : alive;
     int slot = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) slot = (k == q) ? ci[k] : slot;
+    for (int k = 0; k < 8; ++k) slot = (k == e) ? ci[k] : slot;
     if (alive && v != 0ull) atomicAdd(&acc[((int64_t)p * slots + slot) * 5 + i], v);
   }
 }
@@ -4926,8 +5007,8 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
     const unsigned pair_groups = kXcds * ((n + kXcds - 1) / kXcds);
     if (sweep) {
       const int s_max = std::max(w_left, w_top), l_max = std::max(H, W);
-      const int n_row_chunks = (s_max + kSweepRows - 1) / kSweepRows + 1, n_col_chunks = (l_max / 8 + kThreads - 1) / kThreads;
-      MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_sweep, dim3(pair_groups * k * 2 * n_row_chunks * n_col_chunks), dim3(kThreads), 0,
+      const int n_row_chunks = (s_max + kSweepRows - 1) / kSweepRows + 2, n_col_chunks = (l_max / 8 + kThreads - 1) / kThreads;
+      MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_sweep, dim3(pair_groups * k * n_row_chunks * n_col_chunks), dim3(kThreads), 0,
                 ws.desc, status, pair0, n, ws.peaks, ws.cand, ws.acc, ws.n_cand, k, n_row_chunks, n_col_chunks);
       if (subpixel)
         MS_LAUNCH(ctx, "k_ncc_accumulate", k_ncc_accumulate, dim3(pair_groups * kNccChunks), dim3(kThreads), 0, ws.desc, status,
