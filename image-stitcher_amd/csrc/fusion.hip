@@ -741,9 +741,17 @@ __device__ __forceinline__ void fuse_block(TileRef* list, unsigned* queue, unsig
       // the host points both idle offsets at the workspace when the tile or flatfield array holds fewer than 8 values)
       const TileRef* c = list + ((csel >> (5 * r)) & 31u);
       const int64_t at = yW + x;
+#if defined(MS_FUSE_ABLATE) && MS_FUSE_ABLATE == 4  /* measurement build: every pixel load of a copy starts on a 4-byte boundary */
+      const int64_t off = (k == 1 ? c->src_base + at : idle_off) & ~(int64_t)1;
+#elif defined(MS_FUSE_ABLATE) && MS_FUSE_ABLATE == 5  /* measurement build: ... on a 16-byte boundary */
+      const int64_t off = (k == 1 ? c->src_base + at : idle_off) & ~(int64_t)7;
+#else
       const int64_t off = k == 1 ? c->src_base + at : idle_off;
+#endif
 #if defined(MS_FUSE_ABLATE) && MS_FUSE_ABLATE == 3  /* measurement build: every flatfield load of a copy falls into one 64 KiB window */
       const int64_t foff = (k == 1 ? c->ff_base + at : idle_foff) & 0x3fff;
+#elif defined(MS_FUSE_ABLATE) && MS_FUSE_ABLATE == 6  /* measurement build: every flatfield load of a copy starts on a 32-byte boundary */
+      const int64_t foff = (k == 1 ? c->ff_base + at : idle_foff) & ~(int64_t)7;
 #else
       const int64_t foff = k == 1 ? c->ff_base + at : idle_foff;
 #endif
