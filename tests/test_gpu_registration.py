@@ -37,6 +37,23 @@ def test_grids_match_reference_golden(reg, golden, fft):
         assert np.array_equal(out[:, 1:].astype(np.int64), g.expected_shift)
 
 
+@pytest.mark.parametrize("grid", [(2, 1, 320, 4096), (1, 2, 4096, 320)])
+@pytest.mark.parametrize("seed", [5, 6, 7, 8])
+def test_long_sides_of_4096_match_the_oracle(reg, grid, seed):
+    """Strips whose long side is 4096: lines of the largest transform, and candidate sums whose rows take two
+    workgroups side by side (a column lag then wraps from one workgroup's part of the row into the other's).  The
+    seeds plant odd and even shifts along the long side."""
+    rows, cols, th, tw = grid
+    g = synth.make_grid(seed, rows, cols, th, tw, overlap=0.2, jitter=5)
+    out, status = reg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 64)
+    out, status = out.cpu().numpy(), status.cpu().numpy()
+    exp, exp_status = oreg.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 64, polish=False)
+    assert np.array_equal(status, exp_status)
+    assert np.array_equal(out[:, 1:], exp[:, 1:])
+    assert np.allclose(out[:, 0], exp[:, 0], rtol=0, atol=1e-9)
+    assert np.array_equal(out[:, 1:].astype(np.int64), g.expected_shift)
+
+
 def test_unsupported_shape_is_an_error(reg):
     """Sides beyond 4096 are refused with an error, never computed wrongly."""
     tiles = np.zeros((2, 16, 4100), dtype=np.uint16)
