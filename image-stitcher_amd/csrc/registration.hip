@@ -1553,7 +1553,12 @@ __global__ __launch_bounds__(N / 8, 4) void k_fft_long_inv_reg(const PairDesc* d
     }
     MS_PIN(tw.p1.x); MS_PIN(tw.p1.y);
     MS_PIN(tw.p2.x); MS_PIN(tw.p2.y);
+#if defined(MS_INV_ABLATE) && MS_INV_ABLATE == 1  /* measurement build: no transform */
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = buf[tid + NT * j];
+#else
     F::inverse(v, buf, tw, tid);
+#endif
     const bool have0 = s0 < S, have1 = s0 + 1 < S;  // an odd S leaves the last transform half empty
     if constexpr (WIDE) {  // (seq == 1: this is the workgroup's only block)
       const int lane = tid & 63, wave = tid >> 6;
@@ -1631,15 +1636,47 @@ __global__ __launch_bounds__(N / 8, 4) void k_fft_long_inv_reg(const PairDesc* d
         }
       }
     }
+    if constexpr (!WIDE) {
+      // This block's two largest first, its values taken in the order of their keys: ">=" is then the whole comparison
+      // (the later of two equal values has the larger key).  e = 2 j + line.
+      double bv1 = -INFINITY, bv2 = -INFINITY;
+      int be1 = -1, be2 = -1;
+      auto take = [&](double x, int e) {
+        const bool g1 = x >= bv1, g2 = x >= bv2;
+        bv2 = g1 ? bv1 : (g2 ? x : bv2);
+        be2 = g1 ? be1 : (g2 ? e : be2);
+        bv1 = g1 ? x : bv1;
+        be1 = g1 ? e : be1;
+      };
+      if (d.transposed) {  // (uniform) key = l * S + s: element by element, line s0 before line s0 + 1
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (have0) take(v[j].x * cmp_scale, 2 * j);
+          if (have1) take(v[j].y * cmp_scale, 2 * j + 1);
+        }
+      } else {  // key = s * N + l: line s0, then line s0 + 1
+        if (have0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) take(v[j].x * cmp_scale, 2 * j);
+        }
+        if (have1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) take(v[j].y * cmp_scale, 2 * j + 1);
+        }
+      }
+      auto key_of = [&](int e) {
+        const int l = tid + NT * (e >> 1);
+        const int key0 = d.transposed ? l * S + s0 : s0 * N + l;
+        return e & 1 ? (d.transposed ? key0 + 1 : key0 + N) : key0;
+      };
+      offer(bv2, key_of(be2), be2 >= 0);
+      offer(bv1, key_of(be1), be1 >= 0);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int l = tid + NT * j;
       const int key0 = d.transposed ? l * S + s0 : s0 * N + l;
       const int key1 = d.transposed ? key0 + 1 : key0 + N;
-      if constexpr (!WIDE) {
-        offer(v[j].x * cmp_scale, key0, have0);
-        offer(v[j].y * cmp_scale, key1, have1);
-      }
       if (want_abs) {
         const double a0v = fabs(v[j].x * scale), a1v = fabs(v[j].y * scale);
         const bool t0 = have0 & first_better(a0v, key0, ba.val, ba.key);
@@ -1653,7 +1690,9 @@ __global__ __launch_bounds__(N / 8, 4) void k_fft_long_inv_reg(const PairDesc* d
     s0 += 2;
     if (++it >= seq || s0 >= S) break;  // the same for every lane
     __syncthreads();                    // the last pass has read the line that the next one replaces
+#if !(defined(MS_INV_ABLATE) && MS_INV_ABLATE == 2)  /* measurement build 2: the first block's lines again */
     load_lines();
+#endif
     __syncthreads();
   }
   ba.loc = ba.key >= 0 ? 0 : -1;
