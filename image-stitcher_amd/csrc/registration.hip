@@ -384,6 +384,54 @@ __global__ void k_transpose_strips(const uint16_t* tiles, int64_t tile_pitch, in
   }
 }
 
+// Streamed once: the intermediate spectra are written by one pass and read by the next, a whole pass of pairs later.
+// MS_REG_NT (bit mask) marks those accesses non-temporal: 1 = stores of the forward long pass, 2 = loads and
+// 4 = stores of the column pass, 8 = loads of the inverse long pass, 16 = strip stores and 32 = tile loads of the
+// staging kernel, 64 = strip loads of the forward long pass.  Measured on 760 pairs of 2048 x 256 strips, same box:
+// 5.40 ms per step with none, 5.28 with 1 (the column pass that follows gains, 1.87 -> 1.72 ms), 5.19 with 1 + 2 + 8;
+// 4 costs the column pass more (1.97 ms) than it gives the inverse pass.  With a flatfield (every strip staged): 5.52 ms
+// with 11, 5.45 with 16 or 32 or both added, 5.50 with 64 added.
+#ifndef MS_REG_NT
+#define MS_REG_NT 59
+#endif
+typedef double nt_d2 __attribute__((ext_vector_type(2)));
+template <int BIT>
+__device__ __forceinline__ double2 stream_load(const double2* p) {
+  if constexpr ((MS_REG_NT & BIT) != 0) {
+    const nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_d2*>(p));
+    return make_double2(v.x, v.y);
+  } else {
+    return *p;
+  }
+}
+template <int BIT>
+__device__ __forceinline__ void stream_store(double2* p, double2 v) {
+  if constexpr ((MS_REG_NT & BIT) != 0) {
+    __builtin_nontemporal_store(nt_d2{v.x, v.y}, reinterpret_cast<nt_d2*>(p));
+  } else {
+    *p = v;
+  }
+}
+
+typedef unsigned nt_u4r __attribute__((ext_vector_type(4)));
+template <int BIT>
+__device__ __forceinline__ uint4 stream_load_u4(const uint4* p) {
+  if constexpr ((MS_REG_NT & BIT) != 0) {
+    const nt_u4r v = __builtin_nontemporal_load(reinterpret_cast<const nt_u4r*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  } else {
+    return *p;
+  }
+}
+template <int BIT>
+__device__ __forceinline__ void stream_store_u4(uint4* p, uint4 v) {
+  if constexpr ((MS_REG_NT & BIT) != 0) {
+    __builtin_nontemporal_store(nt_u4r{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u4r*>(p));
+  } else {
+    *p = v;
+  }
+}
+
 // Same for strips whose sides are multiples of 64 and whose rows are 16-byte
 // aligned: 64 x 64 tiles, 16 bytes per lane in and out.
 // EDGE: the short side (the edge width) is arbitrary: the strip of the first tile then starts at an unaligned
@@ -421,7 +469,7 @@ __global__ __launch_bounds__(256) void k_transpose_strips64(const uint16_t* tile
         v[i] = make_uint4(px[0] | (px[1] << 16), px[2] | (px[3] << 16), px[4] | (px[5] << 16), px[6] | (px[7] << 16));
       }
     } else {
-      v[i] = *reinterpret_cast<const uint4*>(at);
+      v[i] = stream_load_u4<32>(reinterpret_cast<const uint4*>(at));
     }
   }
 #pragma unroll
@@ -444,7 +492,7 @@ __global__ __launch_bounds__(256) void k_transpose_strips64(const uint16_t* tile
     o.y = w4[1];
     o.z = w4[2];
     o.w = w4[3];
-    if (!EDGE || s0 + s < w_left) *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + s) * H + l0 + 8 * sub) = o;
+    if (!EDGE || s0 + s < w_left) stream_store_u4<16>(reinterpret_cast<uint4*>(dst + (int64_t)(s0 + s) * H + l0 + 8 * sub), o);
   }
 }
 
@@ -523,7 +571,7 @@ __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, i
     auto fetch = [&](int p, uint4 (&v)[2]) {
       const uint16_t* img = tiles + (int64_t)pair_idx[2 * p + which] * tile_pitch;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) v[i] = *reinterpret_cast<const uint4*>(img + (int64_t)(l0 + row + 32 * i) * W + x0 + 8 * sub);
+      for (int i = 0; i < 2; ++i) v[i] = stream_load_u4<32>(reinterpret_cast<const uint4*>(img + (int64_t)(l0 + row + 32 * i) * W + x0 + 8 * sub));
     };
     int p = next_pair(p_begin);
     if (!EDGE && p < p_end) fetch(p, cur);
@@ -567,7 +615,7 @@ __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, i
         o.y = w4[1];
         o.z = w4[2];
         o.w = w4[3];
-        *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + sline) * H + l0 + 8 * sub) = o;
+        stream_store_u4<16>(reinterpret_cast<uint4*>(dst + (int64_t)(s0 + sline) * H + l0 + 8 * sub), o);
       }
       __syncthreads();  // the piece has been read out: the next pair may overwrite it
       cur[0] = nxt[0];
@@ -592,7 +640,7 @@ __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, i
       const uint16_t* img = tiles + (int64_t)pair_idx[2 * p + which] * tile_pitch;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
-        v[i] = *reinterpret_cast<const uint4*>(img + (int64_t)(y0 + min(row + 32 * i, S - 1 - s0)) * W + l0 + 8 * sub);
+        v[i] = stream_load_u4<32>(reinterpret_cast<const uint4*>(img + (int64_t)(y0 + min(row + 32 * i, S - 1 - s0)) * W + l0 + 8 * sub));
     };
     int p = next_pair(p_begin);
     if (p < p_end) fetch(p, cur);
@@ -617,7 +665,7 @@ __global__ __launch_bounds__(256) void k_stage_strips64(const uint16_t* tiles, i
         o.y = r4[1];
         o.z = r4[2];
         o.w = r4[3];
-        *reinterpret_cast<uint4*>(dst + (int64_t)(s0 + sline) * W + l0 + 8 * sub) = o;
+        stream_store_u4<16>(reinterpret_cast<uint4*>(dst + (int64_t)(s0 + sline) * W + l0 + 8 * sub), o);
       }
       cur[0] = nxt[0];
       cur[1] = nxt[1];
@@ -795,8 +843,13 @@ __global__ __launch_bounds__(N / 8) void k_fft_long_fwd_reg(const PairDesc* desc
   unsigned pa[8], pb[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    pa[j] = ra[F::NL * j];
-    pb[j] = rb[F::NL * j];
+    if constexpr ((MS_REG_NT & 64) != 0) {
+      pa[j] = __builtin_nontemporal_load(ra + F::NL * j);
+      pb[j] = __builtin_nontemporal_load(rb + F::NL * j);
+    } else {
+      pa[j] = ra[F::NL * j];
+      pb[j] = rb[F::NL * j];
+    }
   }
   double2 v[8];
   if constexpr (WIN) {
@@ -817,7 +870,7 @@ __global__ __launch_bounds__(N / 8) void k_fft_long_fwd_reg(const PairDesc* desc
   const double2* from = buf + F::slot(w * 512 + l);
   double2* to = out + (int64_t)(w * 64 + (l >> 3)) * sp + (l & 7);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) to[(int64_t)(8 * i) * sp] = from[72 * i];
+  for (int i = 0; i < 8; ++i) stream_store<1>(&to[(int64_t)(8 * i) * sp], from[72 * i]);
 }
 
 // The spectra of two strips of INTEGER pixels are integers at the frequencies that are their own negatives (0 or half
@@ -1078,7 +1131,7 @@ __global__ __launch_bounds__(2 * NC * S / 8, NC == 8 ? 4 : 4) void k_fft_short_c
   const double2* src = slabs + (int64_t)blockIdx.y * slab_pair_elems(S, L) + (pos / kSlab) * sp + pos % kSlab;
   double2 v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = src[(q + Q * j) * kSlab];
+  for (int j = 0; j < 8; ++j) v[j] = stream_load<2>(&src[(q + Q * j) * kSlab]);
   double2 tw0[NB];
 #pragma unroll
   for (int k = 0; k < NB; ++k) tw0[k] = roots[q + k * Q];
@@ -1188,7 +1241,7 @@ __global__ __launch_bounds__(2 * NC * S / 8, NC == 8 ? 4 : 4) void k_fft_short_c
   const int Lp = spectrum_pitch<double>(n_stored);
   double2* Z = spectrum + (int64_t)blockIdx.y * S * Lp + col0 + c;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) Z[(int64_t)(q + Q * j) * Lp] = v[j];
+  for (int j = 0; j < 8; ++j) stream_store<4>(&Z[(int64_t)(q + Q * j) * Lp], v[j]);
 }
 
 // Inverse FFT along the long axis, two lines per complex transform, then the
@@ -1498,8 +1551,8 @@ __global__ __launch_bounds__(N / 8, 4) void k_fft_long_inv_reg(const PairDesc* d
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int i = min(e0 + u * NT, n_stored - 1);  // clamp, do not branch around the loads
-        g1[u] = z1[i];
-        g2[u] = z2[i];
+        g1[u] = stream_load<8>(&z1[i]);
+        g2[u] = stream_load<8>(&z2[i]);
         at_pos[u] = stored_pos[i];
         at_mir[u] = mirror_fill[i];
       }
