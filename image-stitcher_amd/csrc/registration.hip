@@ -387,12 +387,14 @@ __global__ void k_transpose_strips(const uint16_t* tiles, int64_t tile_pitch, in
 // Streamed once: the intermediate spectra are written by one pass and read by the next, a whole pass of pairs later.
 // MS_REG_NT (bit mask) marks those accesses non-temporal: 1 = stores of the forward long pass, 2 = loads and
 // 4 = stores of the column pass, 8 = loads of the inverse long pass, 16 = strip stores and 32 = tile loads of the
-// staging kernel, 64 = strip loads of the forward long pass.  Measured on 760 pairs of 2048 x 256 strips, same box:
+// staging kernel, 64 = strip loads of the forward long pass, 128 = slab loads of the subpixel stage's short pass,
+// 256 = the column pass's stores of that stage's copy.  Measured on 760 pairs of 2048 x 256 strips, same box:
 // 5.40 ms per step with none, 5.28 with 1 (the column pass that follows gains, 1.87 -> 1.72 ms), 5.19 with 1 + 2 + 8;
 // 4 costs the column pass more (1.97 ms) than it gives the inverse pass.  With a flatfield (every strip staged): 5.52 ms
-// with 11, 5.45 with 16 or 32 or both added, 5.50 with 64 added.
+// with 11, 5.45 with 16 or 32 or both added, 5.50 with 64 added.  With the subpixel stage: 7.52 ms with 59, 7.35 with 256 added
+// (the column pass 2.24 -> 2.13 ms), 128 changes nothing.
 #ifndef MS_REG_NT
-#define MS_REG_NT 59
+#define MS_REG_NT 315
 #endif
 typedef double nt_d2 __attribute__((ext_vector_type(2)));
 template <int BIT>
@@ -413,6 +415,24 @@ __device__ __forceinline__ void stream_store(double2* p, double2 v) {
   }
 }
 
+typedef float nt_f2 __attribute__((ext_vector_type(2)));
+template <int BIT>
+__device__ __forceinline__ float2 stream_load(const float2* p) {
+  if constexpr ((MS_REG_NT & BIT) != 0) {
+    const nt_f2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f2*>(p));
+    return make_float2(v.x, v.y);
+  } else {
+    return *p;
+  }
+}
+template <int BIT>
+__device__ __forceinline__ void stream_store(float2* p, float2 v) {
+  if constexpr ((MS_REG_NT & BIT) != 0) {
+    __builtin_nontemporal_store(nt_f2{v.x, v.y}, reinterpret_cast<nt_f2*>(p));
+  } else {
+    *p = v;
+  }
+}
 typedef unsigned nt_u4r __attribute__((ext_vector_type(4)));
 template <int BIT>
 __device__ __forceinline__ uint4 stream_load_u4(const uint4* p) {
@@ -812,7 +832,7 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_fwd(const PairDesc* desc,
   const int64_t sp = slab_pitch(S);
   for (int e = tid; e < NF * L; e += kThreads) {
     const int c8 = e % kSlab, f = (e / kSlab) & (NF - 1), slab = (e / kSlab) >> lNF;
-    out[slab * sp + f * kSlab + c8] = buf[addr(f, slab * kSlab + c8)];
+    stream_store<1>(&out[slab * sp + f * kSlab + c8], buf[addr(f, slab * kSlab + c8)]);
   }
   MS_STAMP(0, 3);
 }
@@ -983,7 +1003,7 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
       for (int e0 = tid, k0 = 0; e0 < n_elem; e0 += NT * U, k0 += U) {
         cx<T> r[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) r[u] = src[e0 + u * NT < n_elem ? (k0 + u) * src_step : 0];  // never branch around a load
+        for (int u = 0; u < U; ++u) r[u] = stream_load<2>(&src[e0 + u * NT < n_elem ? (k0 + u) * src_step : 0]);  // never branch around a load
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           MS_PIN(r[u].x);
@@ -1006,7 +1026,7 @@ __global__ __launch_bounds__(NT) void k_fft_short_cps(const PairDesc* desc, cons
     MS_STAMP(1, 1);
     auto from_slabs = [&](int c, int q) {
       const int pos = c < na ? un.a0 + c : un.b0 + (c - na);
-      return Zs[(pos / kSlab) * sp + q * kSlab + pos % kSlab];
+      return stream_load<2>(&Zs[(pos / kSlab) * sp + q * kSlab + pos % kSlab]);
     };
     if constexpr (MIXED)
       mixed_forward_from(buf, rs, lncol, planS, twN, tid, NT, true, from_slabs);
@@ -1212,7 +1232,7 @@ __global__ __launch_bounds__(2 * NC * S / 8, NC == 8 ? 4 : 4) void k_fft_short_c
                               frow4.z & 0xffffu, frow4.z >> 16, frow4.w & 0xffffu, frow4.w >> 16};
     double2* Rs = keep_r + (int64_t)blockIdx.y * slab_pair_elems(S, L) + (pos / kSlab) * sp + pos % kSlab;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) Rs[(int)((frow[m] + S / 2) & (S - 1)) * kSlab] = v[m];
+    for (int m = 0; m < 8; ++m) stream_store<256>(&Rs[(int)((frow[m] + S / 2) & (S - 1)) * kSlab], v[m]);
   }
   // inverse transform of the stored columns: the first adjoint pass starts from the rows a lane holds
   RegFft<512>::butterfly<8, true>(v, mk<double>(1.0, 0.0), false);
@@ -1289,8 +1309,8 @@ __global__ __launch_bounds__(kThreads) void k_fft_long_inv(const PairDesc* desc,
         const int e = min(e0 + u * kThreads, NF * n_stored - 1);  // clamp, do not branch around the loads
         const int f = NF == 1 ? 0 : e / n_stored, i = e - f * n_stored;
         // lines past the last one (odd S, or a last block that is not full) read the last line and count as zero
-        g1[u] = Z[(int64_t)min(s0 + 2 * f, S - 1) * Lp + i];
-        g2[u] = Z[(int64_t)min(s0 + 2 * f + 1, S - 1) * Lp + i];
+        g1[u] = stream_load<8>(&Z[(int64_t)min(s0 + 2 * f, S - 1) * Lp + i]);
+        g2[u] = stream_load<8>(&Z[(int64_t)min(s0 + 2 * f + 1, S - 1) * Lp + i]);
         at_pos[u] = stored_pos[i];
         at_mir[u] = mirror_fill[i];
       }
@@ -2507,7 +2527,11 @@ __global__ __launch_bounds__(kUpsShortThreads) void k_ups_short_reg(const PairDe
 #endif
     const cx<T>* slab = Rs + (pos / kSlab) * sp;
 #pragma unroll
-    for (int u = 0; u < U; ++u) pre[u] = slab[min(tid + u * kUpsShortThreads, Sr * kSlab - 1)];
+    for (int u = 0; u < U; ++u) {
+      const cx<T>* at = slab + min(tid + u * kUpsShortThreads, Sr * kSlab - 1);
+      if constexpr (std::is_same<T, double>::value) pre[u] = stream_load<128>(at);
+      else pre[u] = *at;
+    }
   };
   fetch(slab0, slab_pos[slab0]);
   double av[QS];
