@@ -4574,7 +4574,8 @@ static int reserve_registration(mistitch_ctx* ctx, int n_pairs, int chunk, int s
   if ((rc = ctx->staging.reserve((size_t)stage_slots * staging_elems_per_pair * 2 + 256))) return rc;
   if ((rc = ctx->spectrum.reserve((size_t)chunk * spectrum_bytes_per_pair))) return rc;
   if ((rc = ctx->slabs.reserve((size_t)chunk * slab_bytes_per_pair))) return rc;
-  if ((rc = ctx->partial.reserve((size_t)chunk * partial_stride * sizeof(Peak)))) return rc;
+  // (a call that stages every pair up front also keeps every pair's block lists, and merges them in one launch)
+  if ((rc = ctx->partial.reserve((size_t)std::max(chunk, stage_slots) * partial_stride * sizeof(Peak)))) return rc;
   if ((rc = ctx->peaks.reserve((size_t)n_pairs * kMaxK * sizeof(Peak)))) return rc;
   if ((rc = ctx->cand.reserve((size_t)n_pairs * (n_cand + 1) * sizeof(Cand)))) return rc;
   if ((rc = ctx->acc.reserve((size_t)n_pairs * (n_cand + 1) * 5 * sizeof(unsigned long long)))) return rc;
@@ -5140,23 +5141,32 @@ static int register_pairs_impl(mistitch_ctx* ctx, const uint16_t* tiles, int n_t
     }
   };
   if (stage_all && (rc = stage(0, n_pairs))) return rc;
+  // The block lists of every pass are merged into peaks and candidates by ONE launch behind the last pass when nothing in
+  // between needs them (the subpixel stage does): a launch per pass is a dozen microseconds each for a few of work.
+  const bool merge_at_end = stage_all && !subpixel;
   for (int pair0 = 0; pair0 < n_pairs; pair0 += chunk) {
     const int n = std::min(chunk, n_pairs - pair0);
     if (!stage_all && (rc = stage(pair0, n))) return rc;
+    RegWorkspace wsp = ws;  // this pass's view: its pairs' block lists behind those of the passes before
+    if (merge_at_end) wsp.partial = ws.partial + (int64_t)pair0 * ws.partial_stride;
     if (same_shape) {
       // left strips come from the aligned staging buffer, top strips from the tiles (or from staging too)
-      if ((rc = launch_any(ctx, cfg_left, f64, ws, status, pair0, n, -1, vec_strips, k, nullptr))) return rc;
+      if ((rc = launch_any(ctx, cfg_left, f64, wsp, status, pair0, n, -1, vec_strips, k, nullptr))) return rc;
     } else {
-      if ((rc = launch_any(ctx, cfg_left, f64, ws, status, pair0, n, 1, true, k, nullptr))) return rc;
-      if ((rc = launch_any(ctx, cfg_top, f64, ws, status, pair0, n, 0, vec_strips, k, nullptr))) return rc;
+      if ((rc = launch_any(ctx, cfg_left, f64, wsp, status, pair0, n, 1, true, k, nullptr))) return rc;
+      if ((rc = launch_any(ctx, cfg_top, f64, wsp, status, pair0, n, 0, vec_strips, k, nullptr))) return rc;
     }
-    MS_LAUNCH(ctx, "k_peaks_candidates", k_peaks_candidates, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, ws.partial,
-                       ws.partial_stride, cfg_top.nblk, cfg_left.nblk, k, k, ws.peaks, ws.cand, ws.acc);
+    if (!merge_at_end)
+      MS_LAUNCH(ctx, "k_peaks_candidates", k_peaks_candidates, dim3(n), dim3(kThreads), 0, ws.desc, status, pair0, ws.partial,
+                ws.partial_stride, cfg_top.nblk, cfg_left.nblk, k, k, ws.peaks, ws.cand, ws.acc);
     if (subpixel)
       MS_LAUNCH(ctx, "k_ups_finish", k_ups_finish, dim3((n + 63) / 64), dim3(64), 0, ws.desc, status, pair0, n, ws.partial_ups,
                 ws.n_row_blocks, ws.n_up, ws.uf, ws.ups, ws.cand, ws.n_cand);
     if (!stage_all) candidates(pair0, n);
   }
+  if (merge_at_end)
+    MS_LAUNCH(ctx, "k_peaks_candidates", k_peaks_candidates, dim3(n_pairs), dim3(kThreads), 0, ws.desc, status, 0, ws.partial,
+              ws.partial_stride, cfg_top.nblk, cfg_left.nblk, k, k, ws.peaks, ws.cand, ws.acc);
   if (stage_all) candidates(0, n_pairs);
   MS_LAUNCH(ctx, "k_finalize", k_finalize, dim3((n_pairs + 3) / 4), dim3(256), 0, ws.desc, status, n_pairs, ws.cand, ws.acc,
                      out, status, subpixel ? ws.ups : (const UpsState*)nullptr, ws.n_cand, wide ? 1 : 0, table,
