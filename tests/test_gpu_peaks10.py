@@ -92,3 +92,30 @@ def test_peaks10_with_subpixel_and_passes():
     # identical overlaps score 1.0 on the integer shift already: the subpixel estimate cannot be strictly better
     assert np.array_equal(sub[:, 1:], want[:, 1:])
     assert np.array_equal(want[:, 1:].astype(np.int64), g.expected_shift)
+
+
+def test_candidate_tables_of_a_call_large_enough_for_the_long_row_blocks():
+    """A call of many pairs sums its candidates in workgroups of 64 rows, a small one in workgroups of 32: 144 pairs
+    of 128 x 256 strips with the ten-peak set are enough for the former (several row blocks per strip, cut at the wrap
+    rows of both row lags).  Every kept row of every pair's table against the oracle's."""
+    import torch
+    from image_stitcher_amd import registration
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    g = synth.make_grid(977, 9, 9, 256, 256, overlap=0.3, jitter=6)
+    assert len(g.pair_idx) == 144
+    out, status, table = registration.register_pairs(g.tiles, g.pair_idx, g.pair_dir, 128, peaks10=True, return_candidates=True)
+    out, status, table = out.cpu().numpy(), status.cpu().numpy(), table.cpu().numpy()
+    want, want_st, tables = oreg.register_pairs_peaks10(g.tiles, g.pair_idx, g.pair_dir, 128)
+    assert np.array_equal(status, want_st)
+    for p, t in enumerate(tables):
+        if t is None:
+            continue
+        translations, scores = t
+        kept = np.isfinite(table[p, :, 2])
+        e1_off = out[p, 1:] - want[p, 1:]          # (both in tile coordinates: zero)
+        assert not e1_off.any()
+        strip = table[p, kept]
+        assert np.array_equal(strip[:, :2], np.asarray(translations, dtype=np.float64).reshape(-1, 2)), p
+        assert np.allclose(strip[:, 2], np.asarray(scores, dtype=np.float64), rtol=0, atol=1e-12), p
+    assert np.allclose(out[:, 0], want[:, 0], rtol=0, atol=1e-12)
+    assert np.array_equal(out[:, 1:].astype(np.int64), g.expected_shift)
